@@ -1,0 +1,188 @@
+/* include/lrsc.h -- C ABI of the MI355X-native PacBio self-correction hot path.
+ *
+ * This is the drop-in boundary: the C++ host side (longreadselfcorrect_amd/host,
+ * which mirrors the reference's SequenceProcessFramework / PacBioSelfCorrectionProcess
+ * interface) and any foreign binding call ONLY these entry points.  Plain pointers and
+ * sizes; no C++ or torch types.  Every function returns 0 (LRSC_OK) or a negative
+ * lrsc_status and never calls exit(); the caller owns every buffer it passes.
+ *
+ * Reference interface each group replaces (paths relative to the reference tree):
+ *   lrsc_index_*          RLBWT::RLBWT(file) + initializeFMIndex   SuffixTools/RLBWT.cpp:23-32,109-248
+ *                         (loaded at StriDe/PacBioSelfCorrection.cpp:155-172)
+ *   lrsc_rank             RLBWT::getOcc / getPC                    SuffixTools/RLBWT.h:118-140
+ *   lrsc_bwt_chars        RLBWT::getChar                           SuffixTools/RLBWT.h:42-63
+ *   lrsc_find_kmers       BWTAlgorithms::findInterval/findBiInterval  SuffixTools/BWTAlgorithms.cpp:14-38
+ *   lrsc_kmer_grid        KmerFeature grid of LongReadProbe::getSeqAttribute
+ *                         PacBio/LongReadProbe.cpp:139-150, PacBio/KmerFeature.h:37-64,92-99
+ *   lrsc_find_seeds       LongReadProbe::searchSeedsWithHybridKmers   PacBio/LongReadProbe.cpp:34-117,187-227
+ *   lrsc_extend_walks     LongReadSelfCorrectByOverlap ctor + extendOverlap
+ *                         PacBio/LongReadCorrectByOverlap.cpp:17-95,155-211
+ *   lrsc_correct_batch    PacBioSelfCorrectionProcess::process     PacBio/PacBioSelfCorrectionProcess.cpp:23-206
+ *
+ * Threading: an lrsc_index is immutable after lrsc_index_upload and may be shared;
+ * an lrsc_ctx is single-threaded (one per host worker / per device) and every call on it
+ * is synchronous with respect to the caller unless stated otherwise.
+ */
+#ifndef LRSC_H
+#define LRSC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LRSC_ABI_VERSION 1
+
+typedef enum lrsc_status {
+    LRSC_OK = 0,
+    LRSC_ERR_IO = -1,          /* cannot open / short read                      */
+    LRSC_ERR_FORMAT = -2,      /* "BWT file is not properly formatted"          */
+    LRSC_ERR_ARG = -3,         /* bad argument (null, range, non-ACGT base ...)  */
+    LRSC_ERR_NOMEM = -4,
+    LRSC_ERR_DEVICE = -5,      /* HIP runtime error, no device, not uploaded     */
+    LRSC_ERR_CAPACITY = -6,    /* caller-provided output buffer too small        */
+    LRSC_ERR_UNSUPPORTED = -7
+} lrsc_status;
+
+typedef struct lrsc_index lrsc_index;   /* both strands' FM-index: host image + per-device copies */
+typedef struct lrsc_ctx lrsc_ctx;       /* per-device execution context (stream, scratch, params)  */
+
+/* BWTInterval (SuffixTools/BWTInterval.h:19-81): lower > upper == invalid */
+typedef struct lrsc_interval { int64_t lower, upper; } lrsc_interval;
+/* BiBWTInterval (BWTInterval.h:82-100): fwd = interval of reverse(w) in the .rbwt index,
+ * rvc = interval of reverse-complement(w) in the .bwt index */
+typedef struct lrsc_biinterval { lrsc_interval fwd, rvc; } lrsc_biinterval;
+
+/* which strand's index a raw rank / char query addresses */
+enum { LRSC_BWT = 0, LRSC_RBWT = 1 };
+
+typedef struct lrsc_rank_query {
+    int64_t idx;       /* position in the BWT, -1 allowed (Occ == 0), < num_symbols */
+    uint8_t base;      /* 'A','C','G','T' */
+    uint8_t strand;    /* LRSC_BWT or LRSC_RBWT */
+    uint8_t pad[6];
+} lrsc_rank_query;
+
+typedef struct lrsc_index_info {
+    uint64_t num_strings;        /* reads in the index                        */
+    uint64_t num_symbols;        /* BWT length per strand (bases + num_strings) */
+    uint64_t num_runs[2];        /* RL units on disk (.bwt, .rbwt)              */
+    uint64_t pred_count[2][5];   /* C[$ACGT] per strand                         */
+    uint32_t block_bytes;        /* bytes of one device rank block              */
+    uint32_t block_symbols;      /* BWT symbols covered by one rank block       */
+    uint64_t device_bytes;       /* HBM bytes of both strands once uploaded     */
+} lrsc_index_info;
+
+/* Parameters of the correction path: a POD mirror of PacBioSelfCorrectionParameters +
+ * FMextendParameters + ProbeParameters (PacBio/PacBioSelfCorrectionProcess.h:24-53,
+ * LongReadCorrectByOverlap.h:28-47, LongReadProbe.h:7-40) AFTER the driver's derivation
+ * step (StriDe/PacBioSelfCorrection.cpp:195-206).  Fill with lrsc_params_default(). */
+typedef struct lrsc_params {
+    int32_t pb_coverage;        /* -c, default 90                                  */
+    double  error_rate;         /* -e, default 0.15                                */
+    int32_t start_kmer_len;     /* derived from -g: {5:17, 10:19, 100:21}          */
+    int32_t offset[3];          /* static k-mer size offset per mode (0,1,2)       */
+    int32_t mode;               /* -m, default 1 (only used when manual != 0)      */
+    int32_t manual;             /* -k/-u/-r given                                  */
+    int32_t scan_kmer_len;      /* 19  (LongReadProbe.h:27)                        */
+    int32_t kmer_len_up_bound;  /* 50  (LongReadProbe.h:28)                        */
+    int32_t radius;             /* 100 (LongReadProbe.h:32)                        */
+    float   hh_ratio;           /* 0.6f (LongReadProbe.h:33)                       */
+    int32_t next_target;        /* -n, default 1                                   */
+    int32_t max_leaves;         /* -l, default 32                                  */
+    int32_t idmer_len;          /* -i, default 9                                   */
+    int32_t min_kmer_len;       /* -s, default 13                                  */
+    int32_t split;              /* --split                                         */
+    int32_t no_dp;              /* --nodp                                          */
+} lrsc_params;
+
+/* genome = 5, 10 or 100 (the -g option); coverage = -c.  Reproduces the derivation at
+ * StriDe/PacBioSelfCorrection.cpp:195-200. Returns LRSC_ERR_ARG for another genome value. */
+int lrsc_params_default(int genome, int coverage, lrsc_params* out);
+
+/* ---- index ------------------------------------------------------------------------ */
+/* Parse <prefix>.bwt and <prefix>.rbwt (binary RL format, Appendix C of SURVEY.md) and
+ * build the HBM rank-block image on the host. */
+int lrsc_index_open(const char* bwt_path, const char* rbwt_path, lrsc_index** out);
+/* Same, from RL-unit strings already in memory (units: (rank<<5)|run_len). */
+int lrsc_index_from_units(const uint8_t* bwt_units, uint64_t n_bwt_units,
+                          const uint8_t* rbwt_units, uint64_t n_rbwt_units,
+                          uint64_t num_strings, uint64_t num_symbols, lrsc_index** out);
+int lrsc_index_info_get(const lrsc_index* idx, lrsc_index_info* out);
+/* Copy both strands into `device`'s HBM (idempotent per device). */
+int lrsc_index_upload(lrsc_index* idx, int device);
+void lrsc_index_close(lrsc_index* idx);
+
+/* ---- context ------------------------------------------------------------------------ */
+int lrsc_ctx_create(const lrsc_index* idx, const lrsc_params* params, int device, lrsc_ctx** out);
+void lrsc_ctx_destroy(lrsc_ctx* ctx);
+
+/* ---- FM primitives (host buffers in, host buffers out) --------------------------------- */
+/* out[i] = Occ(base, idx) = #base in BWT[0..idx] of the chosen strand (RLBWT::getOcc). */
+int lrsc_rank(lrsc_ctx* ctx, const lrsc_rank_query* q, uint64_t n, uint64_t* out);
+/* out[i] = BWT[idx[i]] of `strand` as '$','A','C','G','T' (RLBWT::getChar). */
+int lrsc_bwt_chars(lrsc_ctx* ctx, int strand, const uint64_t* idx, uint64_t n, char* out);
+/* n fixed-length k-mers, concatenated (n*k bytes, ACGT). out[i] = findBiInterval(kmer_i):
+ * fwd searched in the rbwt with reverse(w), rvc in the bwt with revcomp(w), each stopping at
+ * the first invalid interval exactly as BWTAlgorithms.cpp:14-31. */
+int lrsc_find_kmers(lrsc_ctx* ctx, const char* kmers, uint32_t k, uint64_t n, lrsc_biinterval* out);
+
+/* ---- LongReadProbe k-mer feature grid -------------------------------------------------- */
+/* reads: concatenated ACGT bytes, read_off: n_reads+1 offsets.  ks: ascending k-mer sizes
+ * (the "pool", e.g. {5,9,15,17,19}), n_k <= 8.  For read r, position p, pool slot j the record
+ * index is (read_off[r] + p) * n_k + j.
+ *   out_iv[rec]      bi-interval of the KmerFeature (base slot by findBiInterval, larger slots by
+ *                    expand(); KmerFeature.h:37-64,92-99)
+ *   out_size[rec]    KmerFeature::size (shorter than ks[j] near the read end: "fake")
+ *   out_count[rec*4] base-composition counters A,C,G,T accumulated during the search
+ * Any of the three outputs may be NULL. */
+int lrsc_kmer_grid(lrsc_ctx* ctx, const char* reads, const uint64_t* read_off, uint32_t n_reads,
+                   const uint8_t* ks, uint32_t n_k,
+                   lrsc_biinterval* out_iv, uint8_t* out_size, uint8_t* out_count);
+
+/* ---- resident batches (inputs already in HBM; what bench.py times) ---------------------- */
+typedef struct lrsc_batch lrsc_batch;
+/* Upload a batch of reads to the ctx's device; validates ACGT. */
+int lrsc_batch_create(lrsc_ctx* ctx, const char* reads, const uint64_t* read_off, uint32_t n_reads,
+                      lrsc_batch** out);
+void lrsc_batch_destroy(lrsc_batch* b);
+/* Run the k-mer grid kernel over the whole resident batch, keeping results on the device
+ * (compact per-position features only).  Timed internally with HIP events on the ctx stream. */
+int lrsc_batch_kmer_grid(lrsc_ctx* ctx, lrsc_batch* b);
+
+/* ---- measurement ------------------------------------------------------------------------- */
+typedef struct lrsc_kernel_stats {
+    uint64_t launches;          /* launches since the last reset                        */
+    double   total_ms;          /* sum of HIP-event durations on the ctx stream          */
+    uint64_t rank_queries;      /* Occ queries issued (algorithmic count)                */
+    uint64_t block_loads;       /* rank-block loads (lower-1/upper in one block count 1) */
+} lrsc_kernel_stats;
+enum { LRSC_K_RANK = 0, LRSC_K_FIND = 1, LRSC_K_GRID = 2, LRSC_K_SEEDS = 3, LRSC_K_EXTEND = 4, LRSC_K_COUNT = 5 };
+int lrsc_ctx_stats(lrsc_ctx* ctx, int kernel, lrsc_kernel_stats* out);
+int lrsc_ctx_stats_reset(lrsc_ctx* ctx);
+/* Block until everything queued on the ctx stream is done. */
+int lrsc_ctx_sync(lrsc_ctx* ctx);
+
+/* ---- synthetic data (deterministic) -------------------------------- */
+/* i.i.d. uniform ACGT genome of `len` bases into out (no terminator). */
+int lrsc_synth_genome(uint64_t seed, uint64_t len, char* out);
+/* Simulated PacBio reads: template of `tmpl_len` bases at a uniform start, random strand,
+ * per-template-base deletion p_del, substitution p_sub, geometric insertion with mean p_ins.
+ * out_bases must hold cap bytes; out_off n_reads+1 entries.  Read i depends only on
+ * (seed, first_read + i), so shards generate disjoint slices independently. */
+int lrsc_synth_reads(uint64_t seed, const char* genome, uint64_t genome_len,
+                     uint64_t first_read, uint32_t n_reads, uint32_t tmpl_len,
+                     double p_del, double p_sub, double p_ins,
+                     char* out_bases, uint64_t cap, uint64_t* out_off);
+
+const char* lrsc_strerror(int status);
+/* last detailed message for the calling thread (e.g. the HIP error string) */
+const char* lrsc_last_error(void);
+int lrsc_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LRSC_H */

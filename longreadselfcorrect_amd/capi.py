@@ -1,0 +1,299 @@
+"""ctypes binding of include/lrsc.h (the C ABI of liblrsc_hip.so).
+
+Plumbing only: numpy arrays in, numpy arrays out.  Everything that computes runs in the HIP
+library; if the library is missing this module raises at import (no fallback path exists).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+from pathlib import Path
+
+import numpy as np
+
+_PKG = Path(__file__).resolve().parent
+_REPO = _PKG.parent
+
+
+def lib_path() -> Path:
+    return _PKG / "_build" / "liblrsc_hip.so"
+
+
+class LrscError(RuntimeError):
+    def __init__(self, status: int, what: str, detail: str):
+        super().__init__(f"{what}: status {status} ({detail})")
+        self.status = status
+        self.detail = detail
+
+
+class Interval(C.Structure):
+    _fields_ = [("lower", C.c_int64), ("upper", C.c_int64)]
+
+
+class BiInterval(C.Structure):
+    _fields_ = [("fwd", Interval), ("rvc", Interval)]
+
+
+class RankQuery(C.Structure):
+    _fields_ = [("idx", C.c_int64), ("base", C.c_uint8), ("strand", C.c_uint8), ("pad", C.c_uint8 * 6)]
+
+
+class IndexInfo(C.Structure):
+    _fields_ = [
+        ("num_strings", C.c_uint64),
+        ("num_symbols", C.c_uint64),
+        ("num_runs", C.c_uint64 * 2),
+        ("pred_count", (C.c_uint64 * 5) * 2),
+        ("block_bytes", C.c_uint32),
+        ("block_symbols", C.c_uint32),
+        ("device_bytes", C.c_uint64),
+    ]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("pb_coverage", C.c_int32),
+        ("error_rate", C.c_double),
+        ("start_kmer_len", C.c_int32),
+        ("offset", C.c_int32 * 3),
+        ("mode", C.c_int32),
+        ("manual", C.c_int32),
+        ("scan_kmer_len", C.c_int32),
+        ("kmer_len_up_bound", C.c_int32),
+        ("radius", C.c_int32),
+        ("hh_ratio", C.c_float),
+        ("next_target", C.c_int32),
+        ("max_leaves", C.c_int32),
+        ("idmer_len", C.c_int32),
+        ("min_kmer_len", C.c_int32),
+        ("split", C.c_int32),
+        ("no_dp", C.c_int32),
+    ]
+
+
+class KernelStats(C.Structure):
+    _fields_ = [
+        ("launches", C.c_uint64),
+        ("total_ms", C.c_double),
+        ("rank_queries", C.c_uint64),
+        ("block_loads", C.c_uint64),
+    ]
+
+
+K_RANK, K_FIND, K_GRID, K_SEEDS, K_EXTEND = range(5)
+BWT, RBWT = 0, 1
+
+RANK_DTYPE = np.dtype([("idx", "<i8"), ("base", "u1"), ("strand", "u1"), ("pad", "u1", (6,))])
+BIIV_DTYPE = np.dtype([("fwd_lower", "<i8"), ("fwd_upper", "<i8"), ("rvc_lower", "<i8"), ("rvc_upper", "<i8")])
+assert RANK_DTYPE.itemsize == C.sizeof(RankQuery) and BIIV_DTYPE.itemsize == C.sizeof(BiInterval)
+
+
+def declared_symbols(header: Path | None = None) -> list[str]:
+    """Every function include/lrsc.h declares (used by the export test)."""
+    text = (header or (_REPO / "include" / "lrsc.h")).read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lrsc_[a-z0-9_]+)\s*\(", text)))
+
+
+def _ptr(a: np.ndarray, t=C.c_void_p):
+    return a.ctypes.data_as(t)
+
+
+class Lrsc:
+    """Thin object wrapper over the C ABI."""
+
+    def __init__(self, path: os.PathLike | None = None):
+        p = Path(path) if path else lib_path()
+        if not p.exists():
+            raise ImportError(
+                f"{p} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+                "There is no CPU fallback for the product path."
+            )
+        self.path = p
+        self.lib = C.CDLL(str(p))
+        L = self.lib
+        L.lrsc_strerror.restype = C.c_char_p
+        L.lrsc_last_error.restype = C.c_char_p
+        for name in declared_symbols():
+            getattr(L, name)  # raises AttributeError if the library does not export it
+        L.lrsc_index_open.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
+        L.lrsc_index_from_units.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64,
+                                            C.POINTER(C.c_void_p)]
+        L.lrsc_index_info_get.argtypes = [C.c_void_p, C.POINTER(IndexInfo)]
+        L.lrsc_index_upload.argtypes = [C.c_void_p, C.c_int]
+        L.lrsc_index_close.argtypes = [C.c_void_p]
+        L.lrsc_index_close.restype = None
+        L.lrsc_params_default.argtypes = [C.c_int, C.c_int, C.POINTER(Params)]
+        L.lrsc_ctx_create.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int, C.POINTER(C.c_void_p)]
+        L.lrsc_ctx_destroy.argtypes = [C.c_void_p]
+        L.lrsc_ctx_destroy.restype = None
+        L.lrsc_ctx_sync.argtypes = [C.c_void_p]
+        L.lrsc_rank.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.lrsc_bwt_chars.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.lrsc_find_kmers.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]
+        L.lrsc_kmer_grid.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]
+        L.lrsc_batch_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.lrsc_batch_destroy.argtypes = [C.c_void_p]
+        L.lrsc_batch_destroy.restype = None
+        L.lrsc_batch_kmer_grid.argtypes = [C.c_void_p, C.c_void_p]
+        L.lrsc_ctx_stats.argtypes = [C.c_void_p, C.c_int, C.POINTER(KernelStats)]
+        L.lrsc_ctx_stats_reset.argtypes = [C.c_void_p]
+        L.lrsc_synth_genome.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p]
+        L.lrsc_synth_reads.argtypes = [C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
+                                       C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_uint64, C.c_void_p]
+
+    # ---- helpers -------------------------------------------------------------------------
+    def check(self, status: int, what: str):
+        if status != 0:
+            raise LrscError(status, what, f"{self.lib.lrsc_strerror(status).decode()}; {self.lib.lrsc_last_error().decode()}")
+
+    def params_default(self, genome: int = 10, coverage: int = 90) -> Params:
+        p = Params()
+        self.check(self.lib.lrsc_params_default(genome, coverage, C.byref(p)), "lrsc_params_default")
+        return p
+
+    # ---- synthetic data -------------------------------------------------------------------
+    def synth_genome(self, seed: int, length: int) -> np.ndarray:
+        out = np.empty(length, dtype=np.uint8)
+        self.check(self.lib.lrsc_synth_genome(seed, length, _ptr(out)), "lrsc_synth_genome")
+        return out
+
+    def synth_reads(self, seed: int, genome: np.ndarray, n_reads: int, tmpl_len: int, first_read: int = 0,
+                    p_del: float = 0.045, p_sub: float = 0.015, p_ins: float = 0.09):
+        """Returns (bases uint8[total], offsets uint64[n_reads+1])."""
+        cap = int(n_reads * tmpl_len * 1.25) + 4096
+        while True:
+            bases = np.empty(cap, dtype=np.uint8)
+            off = np.empty(n_reads + 1, dtype=np.uint64)
+            st = self.lib.lrsc_synth_reads(seed, _ptr(genome), genome.size, first_read, n_reads, tmpl_len,
+                                           p_del, p_sub, p_ins, _ptr(bases), cap, _ptr(off))
+            if st == -6:  # LRSC_ERR_CAPACITY
+                cap *= 2
+                continue
+            self.check(st, "lrsc_synth_reads")
+            return bases[: int(off[-1])].copy(), off
+
+    # ---- index / ctx ------------------------------------------------------------------------
+    def index_open(self, bwt_path: str, rbwt_path: str) -> "Index":
+        h = C.c_void_p()
+        self.check(self.lib.lrsc_index_open(str(bwt_path).encode(), str(rbwt_path).encode(), C.byref(h)), "lrsc_index_open")
+        return Index(self, h)
+
+    def index_from_units(self, bwt_units: np.ndarray, rbwt_units: np.ndarray, num_strings: int, num_symbols: int) -> "Index":
+        h = C.c_void_p()
+        a = np.ascontiguousarray(bwt_units, dtype=np.uint8)
+        b = np.ascontiguousarray(rbwt_units, dtype=np.uint8)
+        self.check(self.lib.lrsc_index_from_units(_ptr(a), a.size, _ptr(b), b.size, num_strings, num_symbols, C.byref(h)),
+                   "lrsc_index_from_units")
+        return Index(self, h)
+
+
+class Index:
+    def __init__(self, api: Lrsc, handle):
+        self.api, self.h = api, handle
+
+    def info(self) -> IndexInfo:
+        out = IndexInfo()
+        self.api.check(self.api.lib.lrsc_index_info_get(self.h, C.byref(out)), "lrsc_index_info_get")
+        return out
+
+    def upload(self, device: int = 0):
+        self.api.check(self.api.lib.lrsc_index_upload(self.h, device), "lrsc_index_upload")
+
+    def ctx(self, params: Params | None = None, device: int = 0) -> "Ctx":
+        h = C.c_void_p()
+        pp = C.byref(params) if params is not None else None
+        self.api.check(self.api.lib.lrsc_ctx_create(self.h, pp, device, C.byref(h)), "lrsc_ctx_create")
+        return Ctx(self.api, self, h)
+
+    def close(self):
+        if self.h:
+            self.api.lib.lrsc_index_close(self.h)
+            self.h = None
+
+
+class Ctx:
+    def __init__(self, api: Lrsc, index: Index, handle):
+        self.api, self.index, self.h = api, index, handle
+
+    def close(self):
+        if self.h:
+            self.api.lib.lrsc_ctx_destroy(self.h)
+            self.h = None
+
+    def rank(self, bases: np.ndarray, idx: np.ndarray, strand: np.ndarray | int) -> np.ndarray:
+        n = len(idx)
+        q = np.zeros(n, dtype=RANK_DTYPE)
+        q["idx"] = idx
+        q["base"] = bases
+        q["strand"] = strand
+        out = np.empty(n, dtype=np.uint64)
+        self.api.check(self.api.lib.lrsc_rank(self.h, _ptr(q), n, _ptr(out)), "lrsc_rank")
+        return out
+
+    def bwt_chars(self, strand: int, idx: np.ndarray) -> np.ndarray:
+        idx = np.ascontiguousarray(idx, dtype=np.uint64)
+        out = np.empty(idx.size, dtype=np.uint8)
+        self.api.check(self.api.lib.lrsc_bwt_chars(self.h, strand, _ptr(idx), idx.size, _ptr(out)), "lrsc_bwt_chars")
+        return out
+
+    def find_kmers(self, kmers: np.ndarray, k: int) -> np.ndarray:
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint8)
+        n = kmers.size // k
+        out = np.empty(n, dtype=BIIV_DTYPE)
+        self.api.check(self.api.lib.lrsc_find_kmers(self.h, _ptr(kmers), k, n, _ptr(out)), "lrsc_find_kmers")
+        return out
+
+    def kmer_grid(self, bases: np.ndarray, off: np.ndarray, ks, want_iv=True, want_size=True, want_count=True):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        ks = np.ascontiguousarray(ks, dtype=np.uint8)
+        total = int(off[-1]) if off.size else 0
+        recs = total * ks.size
+        iv = np.empty(recs, dtype=BIIV_DTYPE) if want_iv else None
+        size = np.empty(recs, dtype=np.uint8) if want_size else None
+        cnt = np.empty((recs, 4), dtype=np.uint8) if want_count else None
+        self.api.check(
+            self.api.lib.lrsc_kmer_grid(self.h, _ptr(bases), _ptr(off), off.size - 1, _ptr(ks), ks.size,
+                                        _ptr(iv) if iv is not None else None,
+                                        _ptr(size) if size is not None else None,
+                                        _ptr(cnt) if cnt is not None else None),
+            "lrsc_kmer_grid")
+        shape = (total, ks.size)
+        return (iv.reshape(shape) if iv is not None else None,
+                size.reshape(shape) if size is not None else None,
+                cnt.reshape(shape + (4,)) if cnt is not None else None)
+
+    def batch(self, bases: np.ndarray, off: np.ndarray) -> "Batch":
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        h = C.c_void_p()
+        self.api.check(self.api.lib.lrsc_batch_create(self.h, _ptr(bases), _ptr(off), off.size - 1, C.byref(h)),
+                       "lrsc_batch_create")
+        return Batch(self, h, int(off[-1]), off.size - 1)
+
+    def stats(self, kernel: int) -> KernelStats:
+        s = KernelStats()
+        self.api.check(self.api.lib.lrsc_ctx_stats(self.h, kernel, C.byref(s)), "lrsc_ctx_stats")
+        return s
+
+    def stats_reset(self):
+        self.api.check(self.api.lib.lrsc_ctx_stats_reset(self.h), "lrsc_ctx_stats_reset")
+
+    def sync(self):
+        self.api.check(self.api.lib.lrsc_ctx_sync(self.h), "lrsc_ctx_sync")
+
+
+class Batch:
+    def __init__(self, ctx: Ctx, handle, total_bases: int, n_reads: int):
+        self.ctx, self.h, self.total_bases, self.n_reads = ctx, handle, total_bases, n_reads
+
+    def kmer_grid(self):
+        self.ctx.api.check(self.ctx.api.lib.lrsc_batch_kmer_grid(self.ctx.h, self.h), "lrsc_batch_kmer_grid")
+
+    def close(self):
+        if self.h:
+            self.ctx.api.lib.lrsc_batch_destroy(self.h)
+            self.h = None

@@ -1,0 +1,583 @@
+// capi.cpp -- implementation of include/lrsc.h on top of the gfx950 kernels.
+//
+// There is deliberately NO CPU fallback in this file: every compute entry point needs a
+// HIP device and returns LRSC_ERR_DEVICE (with the HIP error text in lrsc_last_error())
+// when there is none.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/lrsc.h"
+#include "fm_layout.h"
+#include "kernels.h"
+
+using namespace lrsc;
+
+static thread_local std::string g_last_error;
+
+static int fail(int status, const std::string& msg)
+{
+    g_last_error = msg;
+    return status;
+}
+static int hip_fail(hipError_t e, const char* what)
+{
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return LRSC_ERR_DEVICE;
+}
+#define HIP_TRY(expr)                                              \
+    do {                                                           \
+        hipError_t _e = (expr);                                    \
+        if(_e != hipSuccess) return hip_fail(_e, #expr);           \
+    } while(0)
+
+// ---------------------------------------------------------------------------------------
+// objects
+// ---------------------------------------------------------------------------------------
+struct DeviceCopy {
+    void* blocks[2] = {nullptr, nullptr};
+    uint64_t* dollars[2] = {nullptr, nullptr};
+    FmIndexDev dev{};
+};
+
+struct lrsc_index {
+    StrandImage image[2];     // [LRSC_BWT], [LRSC_RBWT]
+    uint64_t num_strings = 0;
+    uint64_t num_symbols = 0;
+    bool wide = false;
+    std::mutex mu;
+    std::map<int, DeviceCopy> copies;
+};
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    ~DevBuf() { if(p) (void)hipFree(p); }
+    hipError_t reserve(size_t n)
+    {
+        if(n <= cap) return hipSuccess;
+        if(p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T));
+        if(e == hipSuccess) cap = n;
+        return e;
+    }
+};
+
+struct lrsc_ctx {
+    const lrsc_index* index = nullptr;
+    lrsc_params params{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    FmIndexDev fm{};
+    DevCounters* d_ctr = nullptr;
+    lrsc_kernel_stats stats[LRSC_K_COUNT]{};
+    // reusable device scratch
+    DevBuf<uint8_t> s_in, s_codes, s_out;
+    DevBuf<uint64_t> s_off;
+    DevBuf<uint32_t> s_chunk;
+    DevBuf<int> s_flag;
+};
+
+struct lrsc_batch {
+    lrsc_ctx* ctx = nullptr;
+    uint32_t n_reads = 0;
+    uint64_t total_bases = 0;
+    uint8_t* d_codes = nullptr;
+    uint64_t* d_off = nullptr;
+    uint32_t* d_chunk = nullptr;
+    // compact grid features (resident)
+    uint32_t n_k = 0;
+    uint8_t ks[kMaxPool]{};
+    int32_t* d_freq = nullptr;
+    uint8_t* d_base_counted = nullptr;
+};
+
+// ---------------------------------------------------------------------------------------
+// misc
+// ---------------------------------------------------------------------------------------
+extern "C" const char* lrsc_strerror(int status)
+{
+    switch(status) {
+        case LRSC_OK: return "ok";
+        case LRSC_ERR_IO: return "I/O error";
+        case LRSC_ERR_FORMAT: return "BWT file is not properly formatted";
+        case LRSC_ERR_ARG: return "invalid argument";
+        case LRSC_ERR_NOMEM: return "out of memory";
+        case LRSC_ERR_DEVICE: return "HIP device error";
+        case LRSC_ERR_CAPACITY: return "output buffer too small";
+        case LRSC_ERR_UNSUPPORTED: return "unsupported";
+        default: return "unknown error";
+    }
+}
+extern "C" const char* lrsc_last_error(void) { return g_last_error.c_str(); }
+extern "C" int lrsc_abi_version(void) { return LRSC_ABI_VERSION; }
+
+extern "C" int lrsc_params_default(int genome, int coverage, lrsc_params* out)
+{
+    if(!out) return fail(LRSC_ERR_ARG, "null params");
+    int order;
+    switch(genome) {                                  // opt::order, PacBioSelfCorrection.cpp:104
+        case 5: order = 0; break;
+        case 10: order = 1; break;
+        case 100: order = 2; break;
+        default: return fail(LRSC_ERR_ARG, "genome must be 5, 10 or 100");
+    }
+    static const int size[3] = {17, 19, 21};         // opt::size, :105
+    std::memset(out, 0, sizeof(*out));
+    out->pb_coverage = coverage;
+    out->error_rate = 0.15;
+    out->start_kmer_len = size[order];               // :197
+    out->offset[0] = 0;
+    out->offset[1] = 2 * std::min(std::max(coverage / 30 - 1, 0), order + 1);   // :198
+    out->offset[2] = -2 * (order + 1);               // :199
+    out->mode = 1;
+    out->manual = 0;
+    out->scan_kmer_len = 19;
+    out->kmer_len_up_bound = 50;
+    out->radius = 100;
+    out->hh_ratio = 0.6f;
+    out->next_target = 1;
+    out->max_leaves = 32;
+    out->idmer_len = 9;
+    out->min_kmer_len = 13;
+    out->split = 0;
+    out->no_dp = 0;
+    return LRSC_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// index
+// ---------------------------------------------------------------------------------------
+static int index_from_units_impl(const uint8_t* u0, uint64_t n0, const uint8_t* u1, uint64_t n1,
+                                 uint64_t num_strings, uint64_t num_symbols, lrsc_index** out)
+{
+    lrsc_index* idx = new(std::nothrow) lrsc_index();
+    if(!idx) return fail(LRSC_ERR_NOMEM, "lrsc_index");
+    idx->num_strings = num_strings;
+    idx->num_symbols = num_symbols;
+    idx->wide = num_symbols >= (1ull << 31);
+    int st[2] = {LRSC_OK, LRSC_OK};
+    std::string err[2];
+    const uint8_t* us[2] = {u0, u1};
+    const uint64_t ns[2] = {n0, n1};
+    // the two strands are independent: build them on two host threads
+    std::thread t([&]() { st[1] = build_strand_image(us[1], ns[1], num_symbols, idx->wide, idx->image[1], err[1]); });
+    st[0] = build_strand_image(us[0], ns[0], num_symbols, idx->wide, idx->image[0], err[0]);
+    t.join();
+    for(int s = 0; s < 2; ++s)
+        if(st[s] != LRSC_OK) { const int r = fail(st[s], err[s]); delete idx; return r; }
+    if(idx->image[0].dollars.size() != num_strings || idx->image[1].dollars.size() != num_strings) {
+        delete idx;
+        return fail(LRSC_ERR_FORMAT, "number of '$' rows differs from the number of strings in the header");
+    }
+    *out = idx;
+    return LRSC_OK;
+}
+
+extern "C" int lrsc_index_from_units(const uint8_t* bwt_units, uint64_t n_bwt_units, const uint8_t* rbwt_units,
+                                     uint64_t n_rbwt_units, uint64_t num_strings, uint64_t num_symbols,
+                                     lrsc_index** out)
+{
+    if(!bwt_units || !rbwt_units || !out || num_symbols == 0) return fail(LRSC_ERR_ARG, "null/empty index input");
+    return index_from_units_impl(bwt_units, n_bwt_units, rbwt_units, n_rbwt_units, num_strings, num_symbols, out);
+}
+
+extern "C" int lrsc_index_open(const char* bwt_path, const char* rbwt_path, lrsc_index** out)
+{
+    if(!bwt_path || !rbwt_path || !out) return fail(LRSC_ERR_ARG, "null path");
+    std::vector<uint8_t> u[2];
+    uint64_t nstr[2] = {0, 0}, nsym[2] = {0, 0};
+    std::string err;
+    int st = read_bwt_file(bwt_path, u[0], nstr[0], nsym[0], err);
+    if(st != LRSC_OK) return fail(st, err);
+    st = read_bwt_file(rbwt_path, u[1], nstr[1], nsym[1], err);
+    if(st != LRSC_OK) return fail(st, err);
+    if(nstr[0] != nstr[1] || nsym[0] != nsym[1]) return fail(LRSC_ERR_FORMAT, ".bwt and .rbwt disagree on strings/symbols");
+    return index_from_units_impl(u[0].data(), u[0].size(), u[1].data(), u[1].size(), nstr[0], nsym[0], out);
+}
+
+extern "C" int lrsc_index_info_get(const lrsc_index* idx, lrsc_index_info* out)
+{
+    if(!idx || !out) return fail(LRSC_ERR_ARG, "null");
+    std::memset(out, 0, sizeof(*out));
+    out->num_strings = idx->num_strings;
+    out->num_symbols = idx->num_symbols;
+    for(int s = 0; s < 2; ++s) {
+        out->num_runs[s] = idx->image[s].n_runs;
+        for(int c = 0; c < 5; ++c) out->pred_count[s][c] = idx->image[s].pred[c];
+        out->device_bytes += idx->image[s].blocks.size() + idx->image[s].dollars.size() * 8;
+    }
+    out->block_bytes = 64;
+    out->block_symbols = idx->wide ? Block64::kSyms : Block32::kSyms;
+    return LRSC_OK;
+}
+
+extern "C" int lrsc_index_upload(lrsc_index* idx, int device)
+{
+    if(!idx) return fail(LRSC_ERR_ARG, "null index");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    if(idx->copies.count(device)) return LRSC_OK;
+    HIP_TRY(hipSetDevice(device));
+    DeviceCopy dc;
+    dc.dev.wide = idx->wide ? 1u : 0u;
+    for(int s = 0; s < 2; ++s) {
+        const StrandImage& im = idx->image[s];
+        HIP_TRY(hipMalloc(&dc.blocks[s], im.blocks.size()));
+        HIP_TRY(hipMemcpy(dc.blocks[s], im.blocks.data(), im.blocks.size(), hipMemcpyHostToDevice));
+        const size_t db = std::max<size_t>(im.dollars.size(), 1) * sizeof(uint64_t);
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dc.dollars[s]), db));
+        if(!im.dollars.empty())
+            HIP_TRY(hipMemcpy(dc.dollars[s], im.dollars.data(), im.dollars.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+        FmStrand& fs = dc.dev.strand[s];
+        fs.blocks = dc.blocks[s];
+        fs.dollars = dc.dollars[s];
+        fs.n_dollars = im.dollars.size();
+        fs.n_symbols = im.n_symbols;
+        fs.n_blocks = im.n_blocks;
+        for(int c = 0; c < 5; ++c) fs.pred[c] = im.pred[c];
+    }
+    idx->copies[device] = dc;
+    return LRSC_OK;
+}
+
+extern "C" void lrsc_index_close(lrsc_index* idx)
+{
+    if(!idx) return;
+    for(auto& kv : idx->copies) {
+        if(hipSetDevice(kv.first) != hipSuccess) continue;
+        for(int s = 0; s < 2; ++s) {
+            if(kv.second.blocks[s]) (void)hipFree(kv.second.blocks[s]);
+            if(kv.second.dollars[s]) (void)hipFree(kv.second.dollars[s]);
+        }
+    }
+    delete idx;
+}
+
+// ---------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------
+extern "C" int lrsc_ctx_create(const lrsc_index* idx, const lrsc_params* params, int device, lrsc_ctx** out)
+{
+    if(!idx || !out) return fail(LRSC_ERR_ARG, "null");
+    lrsc_index* midx = const_cast<lrsc_index*>(idx);
+    FmIndexDev fm;
+    {
+        std::lock_guard<std::mutex> lock(midx->mu);
+        auto it = midx->copies.find(device);
+        if(it == midx->copies.end()) return fail(LRSC_ERR_DEVICE, "index not uploaded to this device (call lrsc_index_upload)");
+        fm = it->second.dev;
+    }
+    HIP_TRY(hipSetDevice(device));
+    lrsc_ctx* ctx = new(std::nothrow) lrsc_ctx();
+    if(!ctx) return fail(LRSC_ERR_NOMEM, "lrsc_ctx");
+    ctx->index = idx;
+    ctx->device = device;
+    ctx->fm = fm;
+    if(params) ctx->params = *params;
+    else (void)lrsc_params_default(10, 90, &ctx->params);
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if(e == hipSuccess) e = hipEventCreate(&ctx->ev0);
+    if(e == hipSuccess) e = hipEventCreate(&ctx->ev1);
+    if(e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_ctr), sizeof(DevCounters));
+    if(e == hipSuccess) e = hipMemset(ctx->d_ctr, 0, sizeof(DevCounters));
+    if(e != hipSuccess) { lrsc_ctx_destroy(ctx); return hip_fail(e, "lrsc_ctx_create"); }
+    *out = ctx;
+    return LRSC_OK;
+}
+
+extern "C" void lrsc_ctx_destroy(lrsc_ctx* ctx)
+{
+    if(!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if(ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if(ctx->d_ctr) (void)hipFree(ctx->d_ctr);
+    if(ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if(ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if(ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int lrsc_ctx_sync(lrsc_ctx* ctx)
+{
+    if(!ctx) return fail(LRSC_ERR_ARG, "null ctx");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return LRSC_OK;
+}
+
+// Bracket one kernel launch with HIP events on the ctx stream and fold the device counters
+// into the per-kernel stats.  `launch` enqueues on ctx->stream.
+template <class F>
+static int timed_launch(lrsc_ctx* ctx, int which, F&& launch)
+{
+    HIP_TRY(hipMemsetAsync(ctx->d_ctr, 0, sizeof(DevCounters), ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    hipError_t e = launch();
+    if(e != hipSuccess) return hip_fail(e, "kernel launch");
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_TRY(hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    DevCounters h{};
+    HIP_TRY(hipMemcpy(&h, ctx->d_ctr, sizeof(h), hipMemcpyDeviceToHost));
+    lrsc_kernel_stats& s = ctx->stats[which];
+    s.launches += 1;
+    s.total_ms += ms;
+    s.rank_queries += h.rank_queries;
+    s.block_loads += h.block_loads;
+    return LRSC_OK;
+}
+
+extern "C" int lrsc_ctx_stats(lrsc_ctx* ctx, int kernel, lrsc_kernel_stats* out)
+{
+    if(!ctx || !out || kernel < 0 || kernel >= LRSC_K_COUNT) return fail(LRSC_ERR_ARG, "bad stats query");
+    *out = ctx->stats[kernel];
+    return LRSC_OK;
+}
+extern "C" int lrsc_ctx_stats_reset(lrsc_ctx* ctx)
+{
+    if(!ctx) return fail(LRSC_ERR_ARG, "null ctx");
+    for(auto& s : ctx->stats) s = lrsc_kernel_stats{};
+    return LRSC_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// FM primitives
+// ---------------------------------------------------------------------------------------
+extern "C" int lrsc_rank(lrsc_ctx* ctx, const lrsc_rank_query* q, uint64_t n, uint64_t* out)
+{
+    if(!ctx || (!q && n) || (!out && n)) return fail(LRSC_ERR_ARG, "null");
+    if(n == 0) return LRSC_OK;
+    const uint64_t N = ctx->index->num_symbols;
+    for(uint64_t i = 0; i < n; ++i) {
+        const uint8_t b = q[i].base;
+        if(q[i].idx < -1 || q[i].idx >= (int64_t)N || (b != 'A' && b != 'C' && b != 'G' && b != 'T') || q[i].strand > 1)
+            return fail(LRSC_ERR_ARG, "rank query out of range");
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(ctx->s_in.reserve(n * sizeof(lrsc_rank_query)));
+    HIP_TRY(ctx->s_out.reserve(n * sizeof(uint64_t)));
+    HIP_TRY(hipMemcpyAsync(ctx->s_in.p, q, n * sizeof(lrsc_rank_query), hipMemcpyHostToDevice, ctx->stream));
+    const int st = timed_launch(ctx, LRSC_K_RANK, [&]() {
+        return launch_rank(ctx->fm, reinterpret_cast<const lrsc_rank_query*>(ctx->s_in.p), n,
+                           reinterpret_cast<uint64_t*>(ctx->s_out.p), ctx->d_ctr, ctx->stream);
+    });
+    if(st != LRSC_OK) return st;
+    HIP_TRY(hipMemcpy(out, ctx->s_out.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return LRSC_OK;
+}
+
+extern "C" int lrsc_bwt_chars(lrsc_ctx* ctx, int strand, const uint64_t* idx, uint64_t n, char* out)
+{
+    if(!ctx || (!idx && n) || (!out && n) || strand < 0 || strand > 1) return fail(LRSC_ERR_ARG, "null");
+    if(n == 0) return LRSC_OK;
+    const uint64_t N = ctx->index->num_symbols;
+    for(uint64_t i = 0; i < n; ++i)
+        if(idx[i] >= N) return fail(LRSC_ERR_ARG, "BWT position out of range");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(ctx->s_in.reserve(n * sizeof(uint64_t)));
+    HIP_TRY(ctx->s_out.reserve(n));
+    HIP_TRY(hipMemcpyAsync(ctx->s_in.p, idx, n * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    hipError_t e = launch_bwt_chars(ctx->fm, strand, reinterpret_cast<const uint64_t*>(ctx->s_in.p), n,
+                                    reinterpret_cast<char*>(ctx->s_out.p), ctx->stream);
+    if(e != hipSuccess) return hip_fail(e, "bwt_chars");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(out, ctx->s_out.p, n, hipMemcpyDeviceToHost));
+    return LRSC_OK;
+}
+
+// upload ASCII bases, encode to 2-bit codes on the device, reject non-ACGT
+static int upload_and_encode(lrsc_ctx* ctx, const char* ascii, uint64_t n, uint8_t* d_codes)
+{
+    HIP_TRY(ctx->s_in.reserve(n));
+    HIP_TRY(ctx->s_flag.reserve(1));
+    HIP_TRY(hipMemsetAsync(ctx->s_flag.p, 0, sizeof(int), ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->s_in.p, ascii, n, hipMemcpyHostToDevice, ctx->stream));
+    hipError_t e = launch_encode(reinterpret_cast<const char*>(ctx->s_in.p), d_codes, n, ctx->s_flag.p, ctx->stream);
+    if(e != hipSuccess) return hip_fail(e, "encode");
+    int bad = 0;
+    HIP_TRY(hipMemcpyAsync(&bad, ctx->s_flag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    // SeqReader exits on a non-ACGT base (Util/SeqReader.cpp:115-126); the library reports it
+    if(bad) return fail(LRSC_ERR_ARG, "sequence contains a base other than A,C,G,T");
+    return LRSC_OK;
+}
+
+extern "C" int lrsc_find_kmers(lrsc_ctx* ctx, const char* kmers, uint32_t k, uint64_t n, lrsc_biinterval* out)
+{
+    if(!ctx || (!kmers && n) || (!out && n) || k == 0) return fail(LRSC_ERR_ARG, "null / k == 0");
+    if(n == 0) return LRSC_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(ctx->s_codes.reserve(n * k));
+    HIP_TRY(ctx->s_out.reserve(n * sizeof(lrsc_biinterval)));
+    int st = upload_and_encode(ctx, kmers, n * k, ctx->s_codes.p);
+    if(st != LRSC_OK) return st;
+    st = timed_launch(ctx, LRSC_K_FIND, [&]() {
+        return launch_find_kmers(ctx->fm, ctx->s_codes.p, k, n, reinterpret_cast<lrsc_biinterval*>(ctx->s_out.p),
+                                 ctx->d_ctr, ctx->stream);
+    });
+    if(st != LRSC_OK) return st;
+    HIP_TRY(hipMemcpy(out, ctx->s_out.p, n * sizeof(lrsc_biinterval), hipMemcpyDeviceToHost));
+    return LRSC_OK;
+}
+
+static int check_pool(const uint8_t* ks, uint32_t n_k)
+{
+    if(!ks || n_k == 0 || n_k > kMaxPool) return fail(LRSC_ERR_ARG, "pool must hold 1..8 k-mer sizes");
+    for(uint32_t i = 0; i < n_k; ++i) {
+        if(ks[i] == 0 || (i && ks[i] <= ks[i - 1])) return fail(LRSC_ERR_ARG, "pool sizes must be ascending and > 0");
+    }
+    return LRSC_OK;
+}
+
+static int check_offsets(const uint64_t* off, uint32_t n_reads)
+{
+    if(!off) return fail(LRSC_ERR_ARG, "null read offsets");
+    if(off[0] != 0) return fail(LRSC_ERR_ARG, "read_off[0] must be 0");
+    for(uint32_t i = 0; i < n_reads; ++i)
+        if(off[i + 1] < off[i]) return fail(LRSC_ERR_ARG, "read offsets must be non-decreasing");
+    return LRSC_OK;
+}
+
+extern "C" int lrsc_kmer_grid(lrsc_ctx* ctx, const char* reads, const uint64_t* read_off, uint32_t n_reads,
+                              const uint8_t* ks, uint32_t n_k, lrsc_biinterval* out_iv, uint8_t* out_size,
+                              uint8_t* out_count)
+{
+    if(!ctx) return fail(LRSC_ERR_ARG, "null ctx");
+    int st = check_pool(ks, n_k);
+    if(st != LRSC_OK) return st;
+    if(n_reads == 0) return LRSC_OK;
+    st = check_offsets(read_off, n_reads);
+    if(st != LRSC_OK) return st;
+    const uint64_t total = read_off[n_reads];
+    if(total == 0) return LRSC_OK;
+    if(!reads) return fail(LRSC_ERR_ARG, "null reads");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(ctx->s_codes.reserve(total));
+    HIP_TRY(ctx->s_off.reserve(n_reads + 1));
+    const uint64_t n_chunks = (total + (1ull << kChunkShift) - 1) >> kChunkShift;
+    HIP_TRY(ctx->s_chunk.reserve(n_chunks));
+    st = upload_and_encode(ctx, reads, total, ctx->s_codes.p);
+    if(st != LRSC_OK) return st;
+    HIP_TRY(hipMemcpyAsync(ctx->s_off.p, read_off, (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    hipError_t e = launch_chunk_table(ctx->s_off.p, n_reads, total, ctx->s_chunk.p, ctx->stream);
+    if(e != hipSuccess) return hip_fail(e, "chunk_table");
+
+    const uint64_t recs = total * n_k;
+    DevBuf<lrsc_biinterval> d_iv;
+    DevBuf<uint8_t> d_size, d_count;
+    if(out_iv) HIP_TRY(d_iv.reserve(recs));
+    if(out_size) HIP_TRY(d_size.reserve(recs));
+    if(out_count) HIP_TRY(d_count.reserve(recs * 4));
+
+    GridArgs a{};
+    a.codes = ctx->s_codes.p;
+    a.read_off = ctx->s_off.p;
+    a.chunk_read = ctx->s_chunk.p;
+    a.total_bases = total;
+    a.n_reads = n_reads;
+    a.n_k = n_k;
+    for(uint32_t i = 0; i < n_k; ++i) a.ks[i] = ks[i];
+    a.out_iv = d_iv.p;
+    a.out_size = d_size.p;
+    a.out_count = d_count.p;
+    st = timed_launch(ctx, LRSC_K_GRID, [&]() { return launch_kmer_grid(ctx->fm, a, ctx->d_ctr, ctx->stream); });
+    if(st != LRSC_OK) return st;
+    if(out_iv) HIP_TRY(hipMemcpy(out_iv, d_iv.p, recs * sizeof(lrsc_biinterval), hipMemcpyDeviceToHost));
+    if(out_size) HIP_TRY(hipMemcpy(out_size, d_size.p, recs, hipMemcpyDeviceToHost));
+    if(out_count) HIP_TRY(hipMemcpy(out_count, d_count.p, recs * 4, hipMemcpyDeviceToHost));
+    return LRSC_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// resident batches
+// ---------------------------------------------------------------------------------------
+extern "C" void lrsc_batch_destroy(lrsc_batch* b)
+{
+    if(!b) return;
+    if(b->ctx) (void)hipSetDevice(b->ctx->device);
+    if(b->d_codes) (void)hipFree(b->d_codes);
+    if(b->d_off) (void)hipFree(b->d_off);
+    if(b->d_chunk) (void)hipFree(b->d_chunk);
+    if(b->d_freq) (void)hipFree(b->d_freq);
+    if(b->d_base_counted) (void)hipFree(b->d_base_counted);
+    delete b;
+}
+
+extern "C" int lrsc_batch_create(lrsc_ctx* ctx, const char* reads, const uint64_t* read_off, uint32_t n_reads,
+                                 lrsc_batch** out)
+{
+    if(!ctx || !out || n_reads == 0) return fail(LRSC_ERR_ARG, "null / empty batch");
+    int st = check_offsets(read_off, n_reads);
+    if(st != LRSC_OK) return st;
+    const uint64_t total = read_off[n_reads];
+    if(total == 0 || !reads) return fail(LRSC_ERR_ARG, "empty batch");
+    HIP_TRY(hipSetDevice(ctx->device));
+    lrsc_batch* b = new(std::nothrow) lrsc_batch();
+    if(!b) return fail(LRSC_ERR_NOMEM, "lrsc_batch");
+    b->ctx = ctx;
+    b->n_reads = n_reads;
+    b->total_bases = total;
+    const uint64_t n_chunks = (total + (1ull << kChunkShift) - 1) >> kChunkShift;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&b->d_codes), total);
+    if(e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&b->d_off), (n_reads + 1) * sizeof(uint64_t));
+    if(e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&b->d_chunk), n_chunks * sizeof(uint32_t));
+    if(e != hipSuccess) { lrsc_batch_destroy(b); return hip_fail(e, "batch alloc"); }
+    // stream the bases through the ctx staging buffer in slices so host->device staging stays bounded
+    const uint64_t slice = 256ull << 20;
+    for(uint64_t o = 0; o < total; o += slice) {
+        const uint64_t n = std::min(slice, total - o);
+        st = upload_and_encode(ctx, reads + o, n, b->d_codes + o);
+        if(st != LRSC_OK) { lrsc_batch_destroy(b); return st; }
+    }
+    e = hipMemcpyAsync(b->d_off, read_off, (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream);
+    if(e == hipSuccess) e = launch_chunk_table(b->d_off, n_reads, total, b->d_chunk, ctx->stream);
+    if(e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if(e != hipSuccess) { lrsc_batch_destroy(b); return hip_fail(e, "batch upload"); }
+    *out = b;
+    return LRSC_OK;
+}
+
+// pool = {5, 9, scan} U {k + offset[0..2]}  (StriDe/PacBioSelfCorrection.cpp:108,204-206)
+static uint32_t pool_from_params(const lrsc_params& p, uint8_t* ks)
+{
+    std::vector<int> v = {5, 9, p.scan_kmer_len};
+    for(int i = 0; i < 3; ++i) v.push_back(p.start_kmer_len + p.offset[i]);
+    std::sort(v.begin(), v.end());
+    v.erase(std::unique(v.begin(), v.end()), v.end());
+    uint32_t n = 0;
+    for(int x : v) if(x > 0 && x < 256 && n < kMaxPool) ks[n++] = (uint8_t)x;
+    return n;
+}
+
+extern "C" int lrsc_batch_kmer_grid(lrsc_ctx* ctx, lrsc_batch* b)
+{
+    if(!ctx || !b || b->ctx != ctx) return fail(LRSC_ERR_ARG, "batch does not belong to this ctx");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if(b->n_k == 0) {
+        b->n_k = pool_from_params(ctx->params, b->ks);
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_freq), (size_t)b->n_k * b->total_bases * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_base_counted), b->total_bases));
+    }
+    GridArgs a{};
+    a.codes = b->d_codes;
+    a.read_off = b->d_off;
+    a.chunk_read = b->d_chunk;
+    a.total_bases = b->total_bases;
+    a.n_reads = b->n_reads;
+    a.n_k = b->n_k;
+    for(uint32_t i = 0; i < b->n_k; ++i) a.ks[i] = b->ks[i];
+    a.freq = b->d_freq;
+    a.base_counted = b->d_base_counted;
+    return timed_launch(ctx, LRSC_K_GRID, [&]() { return launch_kmer_grid(ctx->fm, a, ctx->d_ctr, ctx->stream); });
+}

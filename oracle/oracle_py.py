@@ -1,0 +1,269 @@
+"""ctypes loaders for the CPU checker libraries -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+
+  Oracle  -> oracle/_build/liblrsc_oracle.so   (our CPU restatement of the reference algorithm)
+  Ref     -> oracle/_ref/liblrsc_ref.so        (the reference's own sources, compiled by oracle/Makefile;
+                                                present only where /root/reference was available at build time)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+BIIV_DTYPE = np.dtype([("fwd_lower", "<i8"), ("fwd_upper", "<i8"), ("rvc_lower", "<i8"), ("rvc_upper", "<i8")])
+SEED_FIELDS = ("start", "len", "max_freq", "repeat", "start_k", "end_k", "start_freq", "end_freq")
+
+HERE = Path(__file__).resolve().parent
+ORACLE_SO = HERE / "_build" / "liblrsc_oracle.so"
+REF_SO = HERE / "_ref" / "liblrsc_ref.so"
+
+
+def build_oracle():
+    subprocess.run(["make", "-C", str(HERE), "oracle"], check=True, capture_output=True)
+
+
+def build_ref(reference: str = "/root/reference") -> bool:
+    if not Path(reference).is_dir():
+        return REF_SO.exists()
+    subprocess.run(["make", "-C", str(HERE), "ref", "-j8", f"REF={reference}"], check=True, capture_output=True)
+    return REF_SO.exists()
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def pack_reads(reads) -> tuple[np.ndarray, np.ndarray]:
+    """list[str|bytes] -> (uint8 bases, uint64 offsets)."""
+    bs = [r.encode() if isinstance(r, str) else bytes(r) for r in reads]
+    off = np.zeros(len(bs) + 1, dtype=np.uint64)
+    if bs:
+        off[1:] = np.cumsum([len(b) for b in bs])
+    bases = np.frombuffer(b"".join(bs), dtype=np.uint8).copy() if bs else np.zeros(0, dtype=np.uint8)
+    return bases, off
+
+
+def unpack_reads(bases: np.ndarray, off: np.ndarray) -> list[str]:
+    buf = bases.tobytes()
+    return [buf[int(off[i]): int(off[i + 1])].decode() for i in range(len(off) - 1)]
+
+
+class Oracle:
+    def __init__(self):
+        if not ORACLE_SO.exists():
+            build_oracle()
+        self.lib = L = C.CDLL(str(ORACLE_SO))
+        L.orc_last_error.restype = C.c_char_p
+        L.orc_bwt_load.restype = C.c_void_p
+        L.orc_bwt_load.argtypes = [C.c_char_p]
+        L.orc_bwt_free.argtypes = [C.c_void_p]
+        for f in ("orc_bwt_num_strings", "orc_bwt_num_symbols", "orc_bwt_num_runs", "orc_bwt_occ_calls"):
+            getattr(L, f).restype = C.c_uint64
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.orc_bwt_pc.restype = C.c_uint64
+        L.orc_bwt_pc.argtypes = [C.c_void_p, C.c_char]
+        L.orc_bwt_occ_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.orc_bwt_char_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.orc_bwt_decode.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_find_intervals.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]
+        L.orc_build_bwt_file.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_char_p]
+        L.orc_threshold_table.argtypes = [C.c_int, C.c_void_p]
+        L.orc_threshold_text.argtypes = [C.c_int, C.c_char_p, C.c_int]
+        L.orc_kmer_grid.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_find_seeds.restype = C.c_int64
+        L.orc_find_seeds.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                     C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+
+    def bwt_load(self, path) -> "OracleBwt":
+        h = self.lib.orc_bwt_load(str(path).encode())
+        if not h:
+            raise RuntimeError(self.lib.orc_last_error().decode())
+        return OracleBwt(self, h)
+
+    def build_bwt_file(self, bases: np.ndarray, off: np.ndarray, reverse_reads: bool, out_path):
+        st = self.lib.orc_build_bwt_file(_p(bases), _p(off), len(off) - 1, int(reverse_reads), str(out_path).encode())
+        if st != 0:
+            raise RuntimeError(self.lib.orc_last_error().decode())
+
+    def build_index(self, bases, off, prefix):
+        """Writes <prefix>.bwt and <prefix>.rbwt."""
+        self.build_bwt_file(bases, off, False, f"{prefix}.bwt")
+        self.build_bwt_file(bases, off, True, f"{prefix}.rbwt")
+
+    def threshold_table(self, cov: int) -> np.ndarray:
+        out = np.zeros((3, 52), dtype=np.float32)
+        self.lib.orc_threshold_table(cov, _p(out))
+        return out
+
+    def threshold_text(self, cov: int) -> str:
+        buf = C.create_string_buffer(8192)
+        n = self.lib.orc_threshold_text(cov, buf, 8192)
+        assert n >= 0
+        return buf.value.decode()
+
+    def kmer_grid(self, bwt: "OracleBwt", rbwt: "OracleBwt", bases, off, ks):
+        """KmerFeature grid; same record layout as lrsc_kmer_grid -> (iv[total,n_k] BIIV, size, count[...,4])."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        ks = np.ascontiguousarray(ks, dtype=np.uint8)
+        total = int(off[-1])
+        iv = np.zeros((total, ks.size), dtype=BIIV_DTYPE)
+        size = np.zeros((total, ks.size), dtype=np.uint8)
+        cnt = np.zeros((total, ks.size, 4), dtype=np.uint8)
+        self.lib.orc_kmer_grid(bwt.h, rbwt.h, _p(bases), _p(off), off.size - 1, _p(ks), ks.size, _p(iv), _p(size), _p(cnt))
+        return iv, size, cnt
+
+    def find_seeds(self, bwt: "OracleBwt", rbwt: "OracleBwt", params, bases, off):
+        """-> (seed_count uint32[n_reads], seeds int32[n,8], attribute int8[total])."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        n_reads = off.size - 1
+        cap = max(1024, int(off[-1]) // 8)
+        count = np.zeros(n_reads, dtype=np.uint32)
+        seeds = np.zeros((cap, 8), dtype=np.int32)
+        attr = np.zeros(int(off[-1]), dtype=np.int8)
+        n = self.lib.orc_find_seeds(bwt.h, rbwt.h, C.byref(params), _p(bases), _p(off), n_reads, _p(count), _p(seeds), cap,
+                                    _p(attr))
+        if n < 0:
+            raise RuntimeError("seed capacity too small")
+        return count, seeds[:n].copy(), attr
+
+
+class OracleBwt:
+    def __init__(self, o: Oracle, h):
+        self.o, self.h = o, h
+
+    @property
+    def num_strings(self):
+        return self.o.lib.orc_bwt_num_strings(self.h)
+
+    @property
+    def num_symbols(self):
+        return self.o.lib.orc_bwt_num_symbols(self.h)
+
+    @property
+    def num_runs(self):
+        return self.o.lib.orc_bwt_num_runs(self.h)
+
+    @property
+    def occ_calls(self):
+        return self.o.lib.orc_bwt_occ_calls(self.h)
+
+    def pc(self, b: str) -> int:
+        return self.o.lib.orc_bwt_pc(self.h, b.encode())
+
+    def occ(self, bases: np.ndarray, idx: np.ndarray) -> np.ndarray:
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        out = np.empty(idx.size, dtype=np.uint64)
+        self.o.lib.orc_bwt_occ_batch(self.h, _p(bases), _p(idx), idx.size, _p(out))
+        return out
+
+    def chars(self, idx: np.ndarray) -> np.ndarray:
+        idx = np.ascontiguousarray(idx, dtype=np.uint64)
+        out = np.empty(idx.size, dtype=np.uint8)
+        self.o.lib.orc_bwt_char_batch(self.h, _p(idx), idx.size, _p(out))
+        return out
+
+    def decode(self) -> np.ndarray:
+        out = np.empty(self.num_symbols, dtype=np.uint8)
+        self.o.lib.orc_bwt_decode(self.h, _p(out))
+        return out
+
+    def find_intervals(self, kmers: np.ndarray, k: int) -> np.ndarray:
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint8)
+        n = kmers.size // k
+        out = np.empty((n, 2), dtype=np.int64)
+        self.o.lib.orc_find_intervals(self.h, _p(kmers), k, n, _p(out))
+        return out
+
+    def close(self):
+        if self.h:
+            self.o.lib.orc_bwt_free(self.h)
+            self.h = None
+
+
+class Ref:
+    """The reference's own object code (only where oracle/_ref was built)."""
+
+    @staticmethod
+    def available() -> bool:
+        return REF_SO.exists()
+
+    def __init__(self):
+        if not REF_SO.exists():
+            raise FileNotFoundError(REF_SO)
+        self.lib = L = C.CDLL(str(REF_SO))
+        L.ref_bwt_load.restype = C.c_void_p
+        L.ref_bwt_load.argtypes = [C.c_char_p]
+        L.ref_bwt_free.argtypes = [C.c_void_p]
+        for f in ("ref_bwt_num_strings", "ref_bwt_num_symbols", "ref_bwt_num_runs"):
+            getattr(L, f).restype = C.c_uint64
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.ref_bwt_pc.restype = C.c_uint64
+        L.ref_bwt_pc.argtypes = [C.c_void_p, C.c_char]
+        L.ref_bwt_occ_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.ref_bwt_char_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.ref_build_bwt.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int]
+        L.ref_threshold_table.argtypes = [C.c_int, C.c_void_p]
+        L.ref_itree_build.restype = C.c_void_p
+        L.ref_itree_build.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        L.ref_itree_free.argtypes = [C.c_void_p]
+        L.ref_itree_query.restype = C.c_uint64
+        L.ref_itree_query.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64]
+
+    def threshold_table(self, cov: int) -> np.ndarray:
+        """One coverage per process: the reference object is an initialise-once singleton."""
+        out = np.zeros((3, 52), dtype=np.float32)
+        self.lib.ref_threshold_table(cov, _p(out))
+        return out
+
+    def bwt_load(self, path) -> "RefBwt":
+        return RefBwt(self, self.lib.ref_bwt_load(str(path).encode()))
+
+    def build_index(self, fasta_path, prefix, threads: int = 4):
+        self.lib.ref_build_bwt(str(fasta_path).encode(), f"{prefix}.bwt".encode(), threads, 0)
+        self.lib.ref_build_bwt(str(fasta_path).encode(), f"{prefix}.rbwt".encode(), threads, 1)
+
+
+class RefBwt:
+    def __init__(self, r: Ref, h):
+        self.r, self.h = r, h
+
+    @property
+    def num_strings(self):
+        return self.r.lib.ref_bwt_num_strings(self.h)
+
+    @property
+    def num_symbols(self):
+        return self.r.lib.ref_bwt_num_symbols(self.h)
+
+    @property
+    def num_runs(self):
+        return self.r.lib.ref_bwt_num_runs(self.h)
+
+    def pc(self, b: str) -> int:
+        return self.r.lib.ref_bwt_pc(self.h, b.encode())
+
+    def occ(self, bases, idx) -> np.ndarray:
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        out = np.empty(idx.size, dtype=np.uint64)
+        self.r.lib.ref_bwt_occ_batch(self.h, _p(bases), _p(idx), idx.size, _p(out))
+        return out
+
+    def chars(self, idx) -> np.ndarray:
+        idx = np.ascontiguousarray(idx, dtype=np.uint64)
+        out = np.empty(idx.size, dtype=np.uint8)
+        self.r.lib.ref_bwt_char_batch(self.h, _p(idx), idx.size, _p(out))
+        return out
+
+    def close(self):
+        if self.h:
+            self.r.lib.ref_bwt_free(self.h)
+            self.h = None

@@ -1,0 +1,116 @@
+// oracle/ref_shim.cpp -- TEST INFRASTRUCTURE ONLY (never linked by the product).
+//
+// A thin extern "C" driver over the *real* reference translation units that
+// compile directly from /root/reference with plain g++ (no config.h, no
+// google-sparsehash, no stand-in headers).  It is built by oracle/Makefile into
+// oracle/_ref/liblrsc_ref.so and used by tests/ to pin the CPU restatement in
+// oracle/*.cpp against the reference's own object code:
+//
+//   * RLBWT load / getOcc / getPC / getChar     SuffixTools/RLBWT.{h,cpp}
+//   * index construction (ropebwt2, IO order)   SuffixTools/BWTCARopebwt.cpp:160-247
+//   * KmerThreshold table                       PacBio/KmerThreshold.cpp:43-79
+//   * IntervalTree build + findOverlapping      PacBio/IntervalTree.cpp:4-48,73-91
+//   * Overlapper::extendMatch                   Thirdparty/overlapper.cpp:421-701
+//
+// Everything above BWTAlgorithms.h (findInterval, LongReadProbe, FM-extend,
+// multiple_alignment) pulls Util/HashMap.h -> generated config.h + google
+// sparsehash and is therefore unbuildable in this image; see DESIGN.md.
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <iostream>
+#include <sstream>
+
+#include "RLBWT.h"
+#include "BWTCARopebwt.h"
+#include "KmerThreshold.h"
+#include "IntervalTree.h"
+#include "overlapper.h"
+
+extern "C" {
+
+// ---- RLBWT -----------------------------------------------------------------
+void* ref_bwt_load(const char* path)
+{
+    return new RLBWT(std::string(path), RLBWT::DEFAULT_SAMPLE_RATE_SMALL);
+}
+void ref_bwt_free(void* h) { delete static_cast<RLBWT*>(h); }
+uint64_t ref_bwt_num_strings(void* h) { return static_cast<RLBWT*>(h)->getNumStrings(); }
+uint64_t ref_bwt_num_symbols(void* h) { return static_cast<RLBWT*>(h)->getBWLen(); }
+uint64_t ref_bwt_num_runs(void* h) { return static_cast<RLBWT*>(h)->getNumRuns(); }
+uint64_t ref_bwt_pc(void* h, char b) { return static_cast<RLBWT*>(h)->getPC(b); }
+// idx is passed signed so that -1 wraps exactly as `interval.lower - 1` does
+// in BWTAlgorithms.h:70.
+uint64_t ref_bwt_occ(void* h, char b, int64_t idx)
+{
+    return static_cast<RLBWT*>(h)->getOcc(b, (size_t)idx);
+}
+void ref_bwt_occ_batch(void* h, const char* b, const int64_t* idx, uint64_t n, uint64_t* out)
+{
+    const RLBWT* p = static_cast<RLBWT*>(h);
+    for(uint64_t i = 0; i < n; ++i) out[i] = p->getOcc(b[i], (size_t)idx[i]);
+}
+char ref_bwt_char(void* h, uint64_t idx) { return static_cast<RLBWT*>(h)->getChar(idx); }
+void ref_bwt_char_batch(void* h, const uint64_t* idx, uint64_t n, char* out)
+{
+    const RLBWT* p = static_cast<RLBWT*>(h);
+    for(uint64_t i = 0; i < n; ++i) out[i] = p->getChar(idx[i]);
+}
+
+// ---- index build (stride index -a ropebwt2; StriDe/index.cpp:164-213) --------
+// do_reverse=0 -> <prefix>.bwt (BWT of the reads), 1 -> .rbwt (BWT of reversed reads)
+int ref_build_bwt(const char* fasta, const char* out, int threads, int do_reverse)
+{
+    BWTCA::runRopebwt2(std::string(fasta), std::string(out), threads, do_reverse != 0);
+    return 0;
+}
+
+// ---- KmerThreshold -------------------------------------------------------------
+// The reference object is a process-wide singleton that can be initialised once
+// (KmerThreshold.cpp:45-46), so one process pins one coverage.  out = 3 x 52 floats.
+int ref_threshold_table(int cov, float* out)
+{
+    KmerThreshold::Instance().initialize(-1, 50, cov, "");
+    for(int mode = 0; mode < 3; ++mode)
+        for(int k = 0; k <= 51; ++k)
+            out[mode * 52 + k] = KmerThreshold::Instance().get(mode, k);
+    return 0;
+}
+
+// ---- IntervalTree ----------------------------------------------------------------
+void* ref_itree_build(const uint64_t* start, const uint64_t* stop, const uint64_t* value, uint64_t n)
+{
+    std::vector<TreeInterval<size_t> > v;
+    v.reserve(n);
+    for(uint64_t i = 0; i < n; ++i) v.emplace_back(start[i], stop[i], value[i]);
+    IntervalTree<size_t>* t = new IntervalTree<size_t>();
+    // same shape as LongReadCorrectByOverlap.cpp:150-151 (construct, then deep-copy assign)
+    *t = IntervalTree<size_t>(v);
+    return t;
+}
+void ref_itree_free(void* h) { delete static_cast<IntervalTree<size_t>*>(h); }
+uint64_t ref_itree_query(void* h, uint64_t start, uint64_t stop, uint64_t* out_values, uint64_t cap)
+{
+    std::vector<TreeInterval<size_t> > r;
+    static_cast<IntervalTree<size_t>*>(h)->findOverlapping(start, stop, r);
+    for(uint64_t i = 0; i < r.size() && i < cap; ++i) out_values[i] = r[i].value;
+    return r.size();
+}
+
+// ---- Overlapper::extendMatch -------------------------------------------------------
+// Returns the fields the DP fallback consumes (LongReadOverlap.cpp:626-659).
+int ref_extend_match(const char* s1, const char* s2, int start1, int start2, int bandwidth,
+                     int* m0s, int* m0e, int* m1s, int* m1e, int* score, int* edit,
+                     int* total_cols, char* cigar, int cigar_cap)
+{
+    SequenceOverlap ov = Overlapper::extendMatch(std::string(s1), std::string(s2), start1, start2, bandwidth);
+    *m0s = ov.match[0].start; *m0e = ov.match[0].end;
+    *m1s = ov.match[1].start; *m1e = ov.match[1].end;
+    *score = ov.score; *edit = ov.edit_distance; *total_cols = ov.total_columns;
+    std::strncpy(cigar, ov.cigar.c_str(), cigar_cap - 1);
+    cigar[cigar_cap - 1] = 0;
+    return (int)ov.cigar.size();
+}
+
+} // extern "C"

@@ -1,0 +1,81 @@
+"""GPU parity of the FM primitives: HIP kernels (through the C ABI) vs the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+@pytest.fixture(scope="module")
+def gpu_ctx(api, small_ds):
+    idx = api.index_open(small_ds.prefix + ".bwt", small_ds.prefix + ".rbwt")
+    idx.upload(0)
+    ctx = idx.ctx(api.params_default(5, 90), 0)
+    yield ctx
+    ctx.close()
+    idx.close()
+
+
+def test_index_info(api, gpu_ctx, oracle, small_ds):
+    info = gpu_ctx.index.info()
+    for s, ext in enumerate(["bwt", "rbwt"]):
+        ob = oracle.bwt_load(f"{small_ds.prefix}.{ext}")
+        assert info.num_strings == ob.num_strings and info.num_symbols == ob.num_symbols
+        assert info.num_runs[s] == ob.num_runs
+        for c, ch in enumerate("$ACGT"):
+            assert info.pred_count[s][c] == ob.pc(ch)
+        ob.close()
+    assert info.block_bytes == 64 and info.block_symbols in (128, 192)
+
+
+@pytest.mark.parametrize("strand,ext", [(0, "bwt"), (1, "rbwt")])
+def test_rank_matches_oracle(gpu_ctx, oracle, small_ds, strand, ext):
+    ob = oracle.bwt_load(f"{small_ds.prefix}.{ext}")
+    n = ob.num_symbols
+    rng = np.random.default_rng(11 + strand)
+    edge = np.array([-1, 0, 1, 127, 128, 129, 191, 192, 193, 383, 384, n - 2, n - 1], dtype=np.int64)
+    idx = np.concatenate([edge, rng.integers(-1, n, size=300_000)])
+    # every block boundary region once as well
+    idx = np.concatenate([idx, np.arange(-1, min(n, 4096), dtype=np.int64)])
+    bases = rng.choice(ACGT, size=idx.size)
+    got = gpu_ctx.rank(bases, idx, strand)
+    np.testing.assert_array_equal(got, ob.occ(bases, idx))
+    ob.close()
+
+
+@pytest.mark.parametrize("strand,ext", [(0, "bwt"), (1, "rbwt")])
+def test_bwt_chars_match_oracle(gpu_ctx, oracle, small_ds, strand, ext):
+    ob = oracle.bwt_load(f"{small_ds.prefix}.{ext}")
+    n = ob.num_symbols
+    pos = np.arange(0, n, dtype=np.uint64)          # the whole BWT, '$' rows included
+    got = gpu_ctx.bwt_chars(strand, pos)
+    np.testing.assert_array_equal(got, ob.decode())
+    assert (got == ord("$")).sum() == ob.num_strings
+    ob.close()
+
+
+@pytest.mark.parametrize("k", [1, 5, 9, 13, 19, 31])
+def test_find_kmers_matches_oracle(gpu_ctx, oracle, small_ds, k):
+    """findBiInterval: fwd in the rbwt with reverse(w), rvc in the bwt with revcomp(w) (BWTAlgorithms.cpp:32-38)."""
+    rng = np.random.default_rng(100 + k)
+    bases, off = small_ds.bases, small_ds.off
+    # half real k-mers from the reads (present), half random (mostly absent for large k -> early exit path)
+    starts = rng.integers(0, bases.size - k, size=4000)
+    real = np.stack([bases[s:s + k] for s in starts if not np.any((off > s) & (off < s + k))])
+    rand = rng.choice(ACGT, size=(4000, k))
+    kmers = np.concatenate([real, rand]).astype(np.uint8)
+    got = gpu_ctx.find_kmers(kmers.reshape(-1), k)
+
+    comp = np.zeros(256, dtype=np.uint8)
+    comp[list(b"ACGT")] = list(b"TGCA")
+    ob, orb = oracle.bwt_load(small_ds.prefix + ".bwt"), oracle.bwt_load(small_ds.prefix + ".rbwt")
+    fwd = orb.find_intervals(kmers[:, ::-1].copy().reshape(-1), k)          # reverse(w) in the rbwt
+    rvc = ob.find_intervals(comp[kmers[:, ::-1]].copy().reshape(-1), k)     # revcomp(w) in the bwt
+    np.testing.assert_array_equal(got["fwd_lower"], fwd[:, 0])
+    np.testing.assert_array_equal(got["fwd_upper"], fwd[:, 1])
+    np.testing.assert_array_equal(got["rvc_lower"], rvc[:, 0])
+    np.testing.assert_array_equal(got["rvc_upper"], rvc[:, 1])
+    if k >= 13:
+        assert (fwd[len(real):, 0] > fwd[len(real):, 1]).any()      # the invalid/early-exit path was exercised
+    ob.close(); orb.close()
