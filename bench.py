@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the PacBio self-correction hot path on N MI355X GPUs of one node.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+A "step" is one pass of the device hot path over one resident batch of synthetic reads
+(BASELINE.json configs[1]: 100k x 10 kb reads, 15 % error, over the FM-index of a 90x read set =
+the "1 Gb FM-index").  Reads shard across ranks with the read-only index replicated in every
+GPU's HBM; there is no collective on the data path, only the timing barrier.
+
+One JSON line on stdout (rank 0).  `roofline` prices the dominant kernel (the Occ-rank / k-mer
+grid kernel) by ALGORITHMIC bytes = rank-block loads x 64 B over its HIP-event duration;
+`cpu_baseline` is the CPU oracle (a port of the reference algorithm) timed on this host on a
+bounded sample of the same reads.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+BLOCK_BYTES = 64
+
+
+def log(msg: str):
+    print(f"[bench +{time.time() - T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+T0 = time.time()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--genome-mb", type=float, default=11.1, help="synthetic genome size; 11.1 Mb x 90x = 100k x 10 kb reads")
+    ap.add_argument("--reads", type=int, default=100_000, help="reads per GPU (= index reads on rank 0)")
+    ap.add_argument("--read-len", type=int, default=10_000)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 disables)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device; there is no CPU fallback for the product path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from longreadselfcorrect_amd import Lrsc
+    from longreadselfcorrect_amd.capi import K_GRID
+
+    api = Lrsc()
+    genome_len = int(args.genome_mb * 1e6)
+    n_reads = args.reads
+
+    # ---- setup (untimed): data, index, upload ---------------------------------------------------
+    log(f"rank {rank}: synthetic genome {genome_len / 1e6:.1f} Mb, {n_reads} x {args.read_len} reads")
+    genome = api.synth_genome(0x5EED0001, genome_len)
+    idx_bases, idx_off = api.synth_reads(0x5EED0002, genome, n_reads, args.read_len, first_read=0)
+    n_sym = int(idx_off[-1]) + n_reads
+    log(f"index read set: {int(idx_off[-1]) / 1e6:.1f} Mbases, {n_sym / 1e9:.3f} G symbols per strand; building BWTs on the GPU")
+    t = time.time()
+    units = [api.build_bwt(idx_bases, idx_off, rev, local_rank) for rev in (False, True)]
+    log(f"BWT + rBWT built in {time.time() - t:.1f}s ({units[0].size / 1e6:.0f} M / {units[1].size / 1e6:.0f} M RL units)")
+    t = time.time()
+    index = api.index_from_units(units[0], units[1], n_reads, n_sym)
+    index.upload(local_rank)
+    info = index.info()
+    log(f"rank-block image built + uploaded in {time.time() - t:.1f}s: {info.device_bytes / 1e9:.2f} GB in HBM, "
+        f"{info.block_symbols} symbols per {info.block_bytes}-byte block")
+    params = api.params_default(5, 90)          # -g 5 -c 90: k = 17, pool {5,9,15,17,19}
+    ctx = index.ctx(params, local_rank)
+
+    if rank == 0:
+        bases, off = idx_bases, idx_off          # self-correction: rank 0 corrects the indexed reads themselves
+    else:
+        bases, off = api.synth_reads(0x5EED0002, genome, n_reads, args.read_len, first_read=rank * n_reads)
+    batch = ctx.batch(bases, off)
+    my_bases = int(off[-1])
+    log(f"batch resident in HBM: {my_bases / 1e6:.1f} Mbases")
+
+    def step():
+        batch.kmer_grid()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.stats_reset()
+
+    def fence():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    # max over ranks of the elapsed time; sum over ranks of the bases processed
+    tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    bb = torch.tensor([float(my_bases)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(bb, op=dist.ReduceOp.SUM)
+    elapsed_max = float(tt.item())
+    total_bases = float(bb.item())
+
+    st = ctx.stats(K_GRID)
+    kernel_ms = st.total_ms / max(st.launches, 1)
+    achieved = (st.block_loads / max(st.launches, 1)) * BLOCK_BYTES / (kernel_ms * 1e-3) / 1e9
+
+    result = None
+    if rank == 0:
+        value = total_bases * args.steps / elapsed_max / 1e6
+        result = {
+            "metric": "corrected Mbases/s (whole node)",
+            "value": value,
+            "unit": "Mbases/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int64",
+            "data": "synthetic",
+            "config": {
+                "workload": (f"BASELINE configs[1]: {n_reads} x {args.read_len / 1000:g} kb reads/GPU (15% err: 4.5% del, 1.5% sub, 9% ins) "
+                             f"over the FM-index of the {n_reads}-read 90x set of a {args.genome_mb:g} Mb genome "
+                             f"({n_sym / 1e9:.2f} G symbols/strand), -c 90 -g 5"),
+                "stages_timed": ["LongReadProbe k-mer feature grid (Occ-rank kernel)"],
+                "index_hbm_gb": info.device_bytes / 1e9,
+                "reads_per_gpu": n_reads,
+                "parallelism": f"reads sharded x{world}, index replicated, no data-path collective",
+            },
+            "roofline": {
+                "kernel": "kmer_grid_kernel",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel_ms": kernel_ms,
+                "block_loads_per_launch": st.block_loads / max(st.launches, 1),
+                "rank_queries_per_launch": st.rank_queries / max(st.launches, 1),
+            },
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            result["cpu_baseline"] = cpu_baseline(units, n_reads, n_sym, params, bases, off, args.cpu_seconds)
+        print(json.dumps(result), flush=True)
+
+    batch.close()
+    ctx.close()
+    index.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(units, n_reads, n_sym, params, bases, off, budget_s):
+    """The CPU oracle (port of the reference's per-position KmerFeature grid) on a bounded sample of the same reads."""
+    from oracle import oracle_py
+
+    log("cpu_baseline: loading the index into the CPU oracle (RLBWT markers)")
+    orc = oracle_py.Oracle()
+    ob = orc.bwt_from_units(units[0], n_reads, n_sym)
+    orb = orc.bwt_from_units(units[1], n_reads, n_sym)
+    ks = np.array([5, 9, 15, 17, 19], dtype=np.uint8)
+    # calibrate on 2 reads, then size the sample to the budget
+    t = time.perf_counter()
+    orc.kmer_grid(ob, orb, bases[: int(off[2])], off[:3].copy(), ks, outputs=False)
+    per_read = (time.perf_counter() - t) / 2
+    n = int(max(2, min(len(off) - 1, budget_s / max(per_read, 1e-6))))
+    log(f"cpu_baseline: {per_read * 1e3:.0f} ms/read -> sampling {n} reads")
+    t = time.perf_counter()
+    orc.kmer_grid(ob, orb, bases[: int(off[n])], off[: n + 1].copy(), ks, outputs=False)
+    dt = time.perf_counter() - t
+    return {
+        "value": int(off[n]) / dt / 1e6,
+        "unit": "Mbases/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"first {n} reads ({int(off[n]) / 1e6:.2f} Mbases) of the same batch, same stage (k-mer feature grid), "
+                  f"oracle/ RLBWT restatement, 1 thread, {dt:.1f}s",
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -115,6 +115,20 @@ int lrsc_index_info_get(const lrsc_index* idx, lrsc_index_info* out);
 int lrsc_index_upload(lrsc_index* idx, int device);
 void lrsc_index_close(lrsc_index* idx);
 
+/* ---- index construction (the `stride index -a ropebwt2` step; StriDe/index.cpp:164-213,
+ *      SuffixTools/BWTCARopebwt.cpp:160-247) ------------------------------------------------ */
+/* Builds the multi-string BWT of the reads (reverse_reads == 0 -> the .bwt payload) or of the
+ * reversed reads (reverse_reads != 0 -> the .rbwt payload) on `device` by suffix sorting, sentinels in
+ * input order, and returns it as the reference's RL units ((rank<<5)|run, runs <= 31,
+ * BWTWriterBinary.cpp:50-71).  *units_out is malloc'ed: release with lrsc_buffer_free.
+ * num_symbols == read_off[n_reads] + n_reads. */
+int lrsc_build_bwt(const char* reads, const uint64_t* read_off, uint32_t n_reads, int reverse_reads, int device,
+                   uint8_t** units_out, uint64_t* n_units_out);
+void lrsc_buffer_free(void* p);
+/* 30-byte header + units, the reference's binary .bwt/.rbwt format (BWTWriterBinary.cpp:28-46,82-93). */
+int lrsc_write_bwt_file(const char* path, const uint8_t* units, uint64_t n_units, uint64_t num_strings,
+                        uint64_t num_symbols);
+
 /* ---- context ------------------------------------------------------------------------ */
 int lrsc_ctx_create(const lrsc_index* idx, const lrsc_params* params, int device, lrsc_ctx** out);
 void lrsc_ctx_destroy(lrsc_ctx* ctx);

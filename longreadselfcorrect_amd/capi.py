@@ -124,6 +124,11 @@ class Lrsc:
         L.lrsc_index_upload.argtypes = [C.c_void_p, C.c_int]
         L.lrsc_index_close.argtypes = [C.c_void_p]
         L.lrsc_index_close.restype = None
+        L.lrsc_build_bwt.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_void_p),
+                                     C.POINTER(C.c_uint64)]
+        L.lrsc_buffer_free.argtypes = [C.c_void_p]
+        L.lrsc_buffer_free.restype = None
+        L.lrsc_write_bwt_file.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]
         L.lrsc_params_default.argtypes = [C.c_int, C.c_int, C.POINTER(Params)]
         L.lrsc_ctx_create.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int, C.POINTER(C.c_void_p)]
         L.lrsc_ctx_destroy.argtypes = [C.c_void_p]
@@ -174,6 +179,25 @@ class Lrsc:
                 continue
             self.check(st, "lrsc_synth_reads")
             return bases[: int(off[-1])].copy(), off
+
+    # ---- index construction -------------------------------------------------------------------
+    def build_bwt(self, bases: np.ndarray, off: np.ndarray, reverse_reads: bool, device: int = 0) -> np.ndarray:
+        """GPU suffix sort -> RL units (uint8) of the .bwt (or .rbwt) payload."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        p = C.c_void_p()
+        n = C.c_uint64()
+        self.check(self.lib.lrsc_build_bwt(_ptr(bases), _ptr(off), off.size - 1, int(reverse_reads), device,
+                                           C.byref(p), C.byref(n)), "lrsc_build_bwt")
+        try:
+            return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n.value,)).copy()
+        finally:
+            self.lib.lrsc_buffer_free(p)
+
+    def write_bwt_file(self, path, units: np.ndarray, num_strings: int, num_symbols: int):
+        units = np.ascontiguousarray(units, dtype=np.uint8)
+        self.check(self.lib.lrsc_write_bwt_file(str(path).encode(), _ptr(units), units.size, num_strings, num_symbols),
+                   "lrsc_write_bwt_file")
 
     # ---- index / ctx ------------------------------------------------------------------------
     def index_open(self, bwt_path: str, rbwt_path: str) -> "Index":

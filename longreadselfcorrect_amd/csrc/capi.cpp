@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -22,6 +23,8 @@
 using namespace lrsc;
 
 static thread_local std::string g_last_error;
+
+static int check_offsets(const uint64_t* off, uint32_t n_reads);
 
 static int fail(int status, const std::string& msg)
 {
@@ -261,6 +264,69 @@ extern "C" void lrsc_index_close(lrsc_index* idx)
         }
     }
     delete idx;
+}
+
+// ---------------------------------------------------------------------------------------
+// index construction
+// ---------------------------------------------------------------------------------------
+namespace lrsc {
+int build_bwt_device(const char* reads, const uint64_t* off, uint32_t n_reads, int reverse_reads, int device,
+                     std::vector<uint8_t>& bwt_out, uint32_t* rounds_out, std::string& err);
+}
+
+extern "C" int lrsc_build_bwt(const char* reads, const uint64_t* read_off, uint32_t n_reads, int reverse_reads,
+                              int device, uint8_t** units_out, uint64_t* n_units_out)
+{
+    if(!reads || !units_out || !n_units_out || n_reads == 0) return fail(LRSC_ERR_ARG, "null / empty read set");
+    int st = check_offsets(read_off, n_reads);
+    if(st != LRSC_OK) return st;
+    std::vector<uint8_t> bwt;
+    std::string err;
+    st = build_bwt_device(reads, read_off, n_reads, reverse_reads, device, bwt, nullptr, err);
+    if(st != LRSC_OK) return fail(st, err);
+    // RL-encode as BWTWriterBinary::writeBWChar does: same symbol and run < 31 extends the run
+    uint64_t n_units = 0;
+    {
+        uint8_t prev = 0xFF; unsigned run = 0;
+        for(uint8_t c : bwt) {
+            if(c == prev && run < 31) ++run;
+            else { ++n_units; prev = c; run = 1; }
+        }
+    }
+    uint8_t* units = static_cast<uint8_t*>(std::malloc(n_units ? n_units : 1));
+    if(!units) return fail(LRSC_ERR_NOMEM, "RL units");
+    {
+        uint64_t u = 0; uint8_t prev = 0xFF; unsigned run = 0;
+        for(uint8_t c : bwt) {
+            if(c == prev && run < 31) { ++run; units[u - 1] = (uint8_t)((c << 5) | run); }
+            else { prev = c; run = 1; units[u++] = (uint8_t)((c << 5) | 1); }
+        }
+    }
+    *units_out = units;
+    *n_units_out = n_units;
+    return LRSC_OK;
+}
+
+extern "C" void lrsc_buffer_free(void* p) { std::free(p); }
+
+extern "C" int lrsc_write_bwt_file(const char* path, const uint8_t* units, uint64_t n_units, uint64_t num_strings,
+                                   uint64_t num_symbols)
+{
+    if(!path || (!units && n_units)) return fail(LRSC_ERR_ARG, "null");
+    std::FILE* f = std::fopen(path, "wb");
+    if(!f) return fail(LRSC_ERR_IO, std::string("cannot open ") + path);
+    uint8_t hdr[30];
+    const uint16_t magic = 0xCACA;
+    const int32_t flag = 0;   // BWF_NOFMI
+    std::memcpy(hdr, &magic, 2);
+    std::memcpy(hdr + 2, &num_strings, 8);
+    std::memcpy(hdr + 10, &num_symbols, 8);
+    std::memcpy(hdr + 18, &n_units, 8);
+    std::memcpy(hdr + 26, &flag, 4);
+    bool ok = std::fwrite(hdr, 1, 30, f) == 30;
+    ok = ok && std::fwrite(units, 1, n_units, f) == n_units;
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? LRSC_OK : fail(LRSC_ERR_IO, std::string("short write to ") + path);
 }
 
 // ---------------------------------------------------------------------------------------

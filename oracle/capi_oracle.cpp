@@ -32,6 +32,12 @@ void* orc_bwt_load(const char* path)
     if(!b->load(path, &g_err)) { delete b; return nullptr; }
     return b;
 }
+void* orc_bwt_from_units(const uint8_t* units, uint64_t n_units, uint64_t num_strings, uint64_t num_symbols)
+{
+    RLBwt* b = new RLBwt();
+    b->assign(std::vector<uint8_t>(units, units + n_units), num_strings, num_symbols);
+    return b;
+}
 void orc_bwt_free(void* h) { delete static_cast<RLBwt*>(h); }
 uint64_t orc_bwt_num_strings(void* h) { return static_cast<RLBwt*>(h)->num_strings(); }
 uint64_t orc_bwt_num_symbols(void* h) { return static_cast<RLBwt*>(h)->num_symbols(); }

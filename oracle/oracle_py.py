@@ -61,6 +61,8 @@ class Oracle:
         L.orc_bwt_load.restype = C.c_void_p
         L.orc_bwt_load.argtypes = [C.c_char_p]
         L.orc_bwt_free.argtypes = [C.c_void_p]
+        L.orc_bwt_from_units.restype = C.c_void_p
+        L.orc_bwt_from_units.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]
         for f in ("orc_bwt_num_strings", "orc_bwt_num_symbols", "orc_bwt_num_runs", "orc_bwt_occ_calls"):
             getattr(L, f).restype = C.c_uint64
             getattr(L, f).argtypes = [C.c_void_p]
@@ -85,6 +87,10 @@ class Oracle:
             raise RuntimeError(self.lib.orc_last_error().decode())
         return OracleBwt(self, h)
 
+    def bwt_from_units(self, units: np.ndarray, num_strings: int, num_symbols: int) -> "OracleBwt":
+        units = np.ascontiguousarray(units, dtype=np.uint8)
+        return OracleBwt(self, self.lib.orc_bwt_from_units(_p(units), units.size, num_strings, num_symbols))
+
     def build_bwt_file(self, bases: np.ndarray, off: np.ndarray, reverse_reads: bool, out_path):
         st = self.lib.orc_build_bwt_file(_p(bases), _p(off), len(off) - 1, int(reverse_reads), str(out_path).encode())
         if st != 0:
@@ -106,12 +112,15 @@ class Oracle:
         assert n >= 0
         return buf.value.decode()
 
-    def kmer_grid(self, bwt: "OracleBwt", rbwt: "OracleBwt", bases, off, ks):
+    def kmer_grid(self, bwt: "OracleBwt", rbwt: "OracleBwt", bases, off, ks, outputs: bool = True):
         """KmerFeature grid; same record layout as lrsc_kmer_grid -> (iv[total,n_k] BIIV, size, count[...,4])."""
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         off = np.ascontiguousarray(off, dtype=np.uint64)
         ks = np.ascontiguousarray(ks, dtype=np.uint8)
         total = int(off[-1])
+        if not outputs:      # timing only (bench.py cpu_baseline)
+            self.lib.orc_kmer_grid(bwt.h, rbwt.h, _p(bases), _p(off), off.size - 1, _p(ks), ks.size, None, None, None)
+            return None
         iv = np.zeros((total, ks.size), dtype=BIIV_DTYPE)
         size = np.zeros((total, ks.size), dtype=np.uint8)
         cnt = np.zeros((total, ks.size, 4), dtype=np.uint8)

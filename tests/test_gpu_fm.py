@@ -79,3 +79,69 @@ def test_find_kmers_matches_oracle(gpu_ctx, oracle, small_ds, k):
     if k >= 13:
         assert (fwd[len(real):, 0] > fwd[len(real):, 1]).any()      # the invalid/early-exit path was exercised
     ob.close(); orb.close()
+
+
+def _grid_case(gpu_ctx, oracle, small_ds, bases, off, ks):
+    ob, orb = oracle.bwt_load(small_ds.prefix + ".bwt"), oracle.bwt_load(small_ds.prefix + ".rbwt")
+    want_iv, want_size, want_cnt = oracle.kmer_grid(ob, orb, bases, off, ks)
+    got_iv, got_size, got_cnt = gpu_ctx.kmer_grid(bases, off, ks)
+    for f in ("fwd_lower", "fwd_upper", "rvc_lower", "rvc_upper"):
+        np.testing.assert_array_equal(got_iv[f], want_iv[f], err_msg=f)
+    np.testing.assert_array_equal(got_size, want_size)
+    np.testing.assert_array_equal(got_cnt, want_cnt)
+    ob.close(); orb.close()
+    return want_iv
+
+
+@pytest.mark.parametrize("ks", [[5, 9, 15, 17, 19], [5, 9, 15, 19, 23], [5, 9, 19, 21, 25], [3, 4, 40]])
+def test_kmer_grid_matches_oracle_on_real_reads(gpu_ctx, oracle, small_ds, ks):
+    """LongReadProbe's per-position KmerFeature grid (LongReadProbe.cpp:146-150): intervals, sizes
+    (incl. 'fake' k-mers at the read end) and composition counters, every record bit-exact."""
+    n = 6
+    off = small_ds.off[: n + 1].copy()
+    bases = small_ds.bases[: int(off[-1])]
+    _grid_case(gpu_ctx, oracle, small_ds, bases, off, np.array(ks, dtype=np.uint8))
+
+
+def test_kmer_grid_edge_cases(gpu_ctx, oracle, small_ds):
+    """Ragged batch: empty reads, reads shorter than every k, a read absent from the index (findInterval's
+    early exit, then expand() on invalid intervals), homopolymers, and a read ending exactly at k."""
+    from oracle.oracle_py import pack_reads
+
+    rng = np.random.default_rng(5)
+    foreign = "".join(rng.choice(list("ACGT"), size=400))         # random: k-mers >= ~11 are absent
+    real = small_ds.reads[3]
+    reads = ["", "A", "ACG", real[:5], real[10:28], real[:19], real[:20], "", foreign, "A" * 60, "ACAC" * 15,
+             real[100:400], "T", ""]
+    bases, off = pack_reads(reads)
+    ks = np.array([5, 9, 15, 17, 19], dtype=np.uint8)
+    want = _grid_case(gpu_ctx, oracle, small_ds, bases, off, ks)
+    # the foreign read really exercised invalid intervals in the large slots
+    s, e = int(off[8]), int(off[9])
+    assert (want["fwd_lower"][s:e, 4] > want["fwd_upper"][s:e, 4]).mean() > 0.9
+
+
+def test_non_acgt_is_rejected(gpu_ctx):
+    from longreadselfcorrect_amd import LrscError
+
+    bases = np.frombuffer(b"ACGTNACGT", dtype=np.uint8)
+    off = np.array([0, 9], dtype=np.uint64)
+    with pytest.raises(LrscError) as ei:
+        gpu_ctx.kmer_grid(bases, off, np.array([5], dtype=np.uint8))
+    assert ei.value.status == -3      # LRSC_ERR_ARG, mirrors SeqReader's exit on non-ACGT (Util/SeqReader.cpp:115-126)
+
+
+def test_stats_count_block_loads(gpu_ctx, small_ds):
+    from longreadselfcorrect_amd.capi import K_GRID
+
+    gpu_ctx.stats_reset()
+    off = small_ds.off[:3].copy()
+    bases = small_ds.bases[: int(off[-1])]
+    ks = np.array([5, 9, 15, 17, 19], dtype=np.uint8)
+    gpu_ctx.kmer_grid(bases, off, ks, want_iv=False, want_count=False)
+    st = gpu_ctx.stats(K_GRID)
+    total = int(off[-1])
+    # 74 Occ per interior position for pool {5,9,15,17,19} (SURVEY.md section 3.3): 2 + 4*18
+    assert st.launches == 1 and st.total_ms > 0
+    assert 0.97 * 74 * total <= st.rank_queries <= 74 * total
+    assert (st.rank_queries - 2 * total) // 2 <= st.block_loads <= st.rank_queries

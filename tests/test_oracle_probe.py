@@ -48,7 +48,7 @@ def test_kmer_grid_consistent_with_find_interval(oracle, small_ds):
     for r in range(3):
         s, e = int(sub_off[r]), int(sub_off[r + 1])
         L = e - s
-        for j, k in enumerate(ks):
+        for j, k in enumerate(int(x) for x in ks):
             want_size = np.minimum(k, L - np.arange(L))
             np.testing.assert_array_equal(size[s:e, j], want_size)
             full = np.arange(0, L - k + 1)
