@@ -3,6 +3,9 @@
 // __graft_entry__.smoke() and bench.py's cpu_baseline leg.  Never by the product.
 #include "fm_oracle.hpp"
 #include "probe_oracle.hpp"
+#include "extend_oracle.hpp"
+#include "dp_oracle.hpp"
+#include "process_oracle.hpp"
 #include "../include/lrsc.h"   // POD types only (lrsc_params, lrsc_biinterval); no product code is linked
 
 #include <cstring>
@@ -188,6 +191,148 @@ int64_t orc_find_seeds(void* bwt, void* rbwt, const lrsc_params* p, const char* 
         }
     }
     return (int64_t)total;
+}
+
+
+// ---- IntervalTree (PacBio/IntervalTree.cpp) -----------------------------------------------------
+void* orc_itree_build(const uint64_t* start, const uint64_t* stop, const uint64_t* value, uint64_t n)
+{
+    std::vector<TreeInterval> v;
+    v.reserve(n);
+    for(uint64_t i = 0; i < n; ++i) v.emplace_back(start[i], stop[i], value[i]);
+    IntervalTree* t = new IntervalTree();
+    *t = IntervalTree(v);       // construct, then deep-copy assign (LongReadCorrectByOverlap.cpp:150-151)
+    return t;
+}
+void orc_itree_free(void* h) { delete static_cast<IntervalTree*>(h); }
+uint64_t orc_itree_query(void* h, uint64_t start, uint64_t stop, uint64_t* out_values, uint64_t cap)
+{
+    std::vector<TreeInterval> r;
+    static_cast<IntervalTree*>(h)->findOverlapping(start, stop, r);
+    for(uint64_t i = 0; i < r.size() && i < cap; ++i) out_values[i] = r[i].value;
+    return r.size();
+}
+
+// ---- Overlapper::extendMatch ---------------------------------------------------------------------
+int orc_extend_match(const char* s1, const char* s2, int start1, int start2, int bandwidth, int match, int gap,
+                     int mismatch, int* out7, char* cigar, int cigar_cap)
+{
+    const SequenceOverlap ov = extend_match(s1, s2, start1, start2, bandwidth, match, gap, mismatch);
+    out7[0] = ov.match[0].start; out7[1] = ov.match[0].end; out7[2] = ov.match[1].start; out7[3] = ov.match[1].end;
+    out7[4] = ov.score; out7[5] = ov.edit_distance; out7[6] = ov.total_columns;
+    std::strncpy(cigar, ov.cigar.c_str(), cigar_cap - 1);
+    cigar[cigar_cap - 1] = 0;
+    return (int)ov.cigar.size();
+}
+
+// ---- FM-extend: one seed-pair walk (LongReadSelfCorrectByOverlap) ---------------------------------------
+static FMextendParameters make_fm(const RLBwt* bwt, const RLBwt* rbwt, const lrsc_params* p)
+{
+    FMextendParameters f;                          // PacBioSelfCorrection.cpp:208-215
+    f.indices.bwt = bwt;
+    f.indices.rbwt = rbwt;
+    f.idmerLength = p->idmer_len;
+    f.maxLeaves = p->max_leaves;
+    f.minKmerLength = p->min_kmer_len;
+    f.PBcoverage = (size_t)p->pb_coverage;
+    f.ErrorRate = p->error_rate;
+    return f;
+}
+// Returns extendOverlap's code (1, -1, -2, -3, -4); merged sequence into out (NUL-terminated).
+int orc_extend_walk(void* bwt, void* rbwt, const lrsc_params* p, const char* src, const char* path, const char* trg,
+                    int dis, int initk, int max_overlap, int min_sa_threshold, char* out, int out_cap, uint64_t* stats3)
+{
+    const FMextendParameters f = make_fm(static_cast<RLBwt*>(bwt), static_cast<RLBwt*>(rbwt), p);
+    FMWalkResult2 r;
+    LongReadSelfCorrectByOverlap tree(src, path, trg, dis, (size_t)initk, (size_t)max_overlap, f, (size_t)min_sa_threshold);
+    const int code = tree.extendOverlap(r);
+    if(stats3) { stats3[0] = tree.stats.steps; stats3[1] = tree.stats.leaf_expansions; stats3[2] = tree.stats.refine_calls; }
+    if(code > 0) {
+        if((int)r.mergedSeq.size() + 1 > out_cap) return -100;
+        std::memcpy(out, r.mergedSeq.c_str(), r.mergedSeq.size() + 1);
+    } else if(out_cap > 0)
+        out[0] = 0;
+    return code;
+}
+
+// ---- the whole per-read path (PacBioSelfCorrectionProcess::process + PostProcess) ---------------------------
+struct OrcRun {
+    std::string correct_fa, discard_fa, stats;
+    std::vector<int64_t> counters;     // per read: 10 counters (PacBioSelfCorrectionResult order) + merge flag
+    std::vector<int32_t> walks;        // flat: read, srcStart, trgStart, code, via
+    uint64_t walk_stats[3] = {0, 0, 0};
+};
+
+void* orc_correct_reads(void* bwt, void* rbwt, const lrsc_params* p, const char* bases, const uint64_t* off,
+                        uint32_t n_reads, const char* id_prefix)
+{
+    KmerThreshold thr;
+    thr.initialize(-1, 50, p->pb_coverage);
+    CorrectionParameters cp;
+    cp.indices.bwt = static_cast<RLBwt*>(bwt);
+    cp.indices.rbwt = static_cast<RLBwt*>(rbwt);
+    cp.PBcoverage = p->pb_coverage;
+    cp.ErrorRate = p->error_rate;
+    cp.startKmerLen = p->start_kmer_len;
+    cp.nextTarget = p->next_target;
+    cp.maxLeaves = p->max_leaves;
+    cp.idmerLen = p->idmer_len;
+    cp.minKmerLen = p->min_kmer_len;
+    cp.Split = p->split != 0;
+    cp.NoDp = p->no_dp != 0;
+    cp.FM_params = make_fm(cp.indices.bwt, cp.indices.rbwt, p);
+    cp.probe = make_probe(cp.indices.bwt, cp.indices.rbwt, p, &thr);
+    cp.pool = cp.probe.pool;
+
+    SelfCorrectionProcess proc(cp);
+    SelfCorrectionPostProcess post(cp.Split);
+    OrcRun* run = new OrcRun();
+    for(uint32_t r = 0; r < n_reads; ++r) {
+        const std::string seq(bases + off[r], bases + off[r + 1]);
+        const std::string id = std::string(id_prefix ? id_prefix : "r") + std::to_string(r);
+        const CorrectionResult res = proc.process(id, seq);
+        post.process(id, seq, res);
+        const int64_t c[11] = {res.totalReadsLen, res.correctedLen, res.totalSeedNum, res.totalWalkNum, res.highErrorNum,
+                               res.exceedDepthNum, res.exceedLeaveNum, res.FMNum, res.DPNum, res.seedDis, res.merge ? 1 : 0};
+        run->counters.insert(run->counters.end(), c, c + 11);
+        for(const auto& w : res.walks) {
+            const int32_t v[5] = {(int32_t)r, w.srcStartPos, w.trgStartPos, w.code, w.via};
+            run->walks.insert(run->walks.end(), v, v + 5);
+        }
+        run->walk_stats[0] += res.walk_stats.steps;
+        run->walk_stats[1] += res.walk_stats.leaf_expansions;
+        run->walk_stats[2] += res.walk_stats.refine_calls;
+    }
+    run->correct_fa = post.correct_fa;
+    run->discard_fa = post.discard_fa;
+    run->stats = post.stats_text();
+    return run;
+}
+void orc_run_free(void* h) { delete static_cast<OrcRun*>(h); }
+// which: 0 correct.fa, 1 discard.fa, 2 stats text
+uint64_t orc_run_text(void* h, int which, char* out, uint64_t cap)
+{
+    const OrcRun* r = static_cast<OrcRun*>(h);
+    const std::string& s = which == 0 ? r->correct_fa : which == 1 ? r->discard_fa : r->stats;
+    if(out && cap >= s.size()) std::memcpy(out, s.data(), s.size());
+    return s.size();
+}
+uint64_t orc_run_counters(void* h, int64_t* out, uint64_t cap)
+{
+    const OrcRun* r = static_cast<OrcRun*>(h);
+    if(out && cap >= r->counters.size()) std::memcpy(out, r->counters.data(), r->counters.size() * 8);
+    return r->counters.size();
+}
+uint64_t orc_run_walks(void* h, int32_t* out, uint64_t cap)
+{
+    const OrcRun* r = static_cast<OrcRun*>(h);
+    if(out && cap >= r->walks.size()) std::memcpy(out, r->walks.data(), r->walks.size() * 4);
+    return r->walks.size();
+}
+void orc_run_walk_stats(void* h, uint64_t* out3)
+{
+    const OrcRun* r = static_cast<OrcRun*>(h);
+    for(int i = 0; i < 3; ++i) out3[i] = r->walk_stats[i];
 }
 
 } // extern "C"

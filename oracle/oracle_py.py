@@ -81,6 +81,59 @@ class Oracle:
         L.orc_find_seeds.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                      C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
 
+    # ---- interval tree / DP / FM-extend / whole path -----------------------------------------------
+    def _decl_late(self):
+        L = self.lib
+        if getattr(self, "_late", False):
+            return
+        self._late = True
+        L.orc_itree_build.restype = C.c_void_p
+        L.orc_itree_build.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        L.orc_itree_free.argtypes = [C.c_void_p]
+        L.orc_itree_query.restype = C.c_uint64
+        L.orc_itree_query.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64]
+        L.orc_extend_match.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_char_p, C.c_int]
+        L.orc_extend_walk.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int,
+                                      C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_void_p]
+        L.orc_correct_reads.restype = C.c_void_p
+        L.orc_correct_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_char_p]
+        L.orc_run_free.argtypes = [C.c_void_p]
+        L.orc_run_text.restype = C.c_uint64
+        L.orc_run_text.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
+        L.orc_run_counters.restype = C.c_uint64
+        L.orc_run_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        L.orc_run_walks.restype = C.c_uint64
+        L.orc_run_walks.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        L.orc_run_walk_stats.argtypes = [C.c_void_p, C.c_void_p]
+
+    def itree_query_all(self, start, stop, value, queries):
+        """Build the tree over (start, stop, value) and return, per query (qs, qe), the values findOverlapping yields in order."""
+        self._decl_late()
+        return _itree_query_all(self.lib, "orc", start, stop, value, queries)
+
+    def extend_match(self, s1: str, s2: str, start1: int, start2: int, bandwidth: int = 200, scores=(1, -1, -8)):
+        self._decl_late()
+        return _extend_match(self.lib.orc_extend_match, s1, s2, start1, start2, bandwidth, scores)
+
+    def extend_walk(self, bwt, rbwt, params, src: str, path: str, trg: str, dis: int, initk: int, max_overlap: int,
+                    min_sa: int):
+        """One LongReadSelfCorrectByOverlap walk -> (code, mergedSeq, (steps, leaf_expansions, refine_calls))."""
+        self._decl_late()
+        cap = len(src) + 3 * len(path) + len(trg) + 4096
+        out = C.create_string_buffer(cap)
+        st = np.zeros(3, dtype=np.uint64)
+        code = self.lib.orc_extend_walk(bwt.h, rbwt.h, C.byref(params), src.encode(), path.encode(), trg.encode(), dis,
+                                        initk, max_overlap, min_sa, out, cap, _p(st))
+        return code, out.value.decode(), tuple(int(x) for x in st)
+
+    def correct_reads(self, bwt, rbwt, params, bases, off, id_prefix: str = "r") -> "OracleRun":
+        self._decl_late()
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        h = self.lib.orc_correct_reads(bwt.h, rbwt.h, C.byref(params), _p(bases), _p(off), off.size - 1, id_prefix.encode())
+        return OracleRun(self, h)
+
     def bwt_load(self, path) -> "OracleBwt":
         h = self.lib.orc_bwt_load(str(path).encode())
         if not h:
@@ -141,6 +194,83 @@ class Oracle:
         if n < 0:
             raise RuntimeError("seed capacity too small")
         return count, seeds[:n].copy(), attr
+
+
+def _itree_query_all(lib, prefix, start, stop, value, queries):
+    start = np.ascontiguousarray(start, dtype=np.uint64)
+    stop = np.ascontiguousarray(stop, dtype=np.uint64)
+    value = np.ascontiguousarray(value, dtype=np.uint64)
+    build, free, query = (getattr(lib, f"{prefix}_itree_{f}") for f in ("build", "free", "query"))
+    h = build(_p(start), _p(stop), _p(value), start.size)
+    out = []
+    buf = np.zeros(max(16, start.size), dtype=np.uint64)
+    for qs, qe in queries:
+        n = query(h, int(qs), int(qe), _p(buf), buf.size)
+        out.append(buf[:n].copy())
+    free(h)
+    return out
+
+
+def _extend_match(fn, s1, s2, start1, start2, bandwidth, scores):
+    out7 = np.zeros(7, dtype=np.int32)
+    cig = C.create_string_buffer(4 * (len(s1) + len(s2)) + 64)
+    fn(s1.encode(), s2.encode(), start1, start2, bandwidth, scores[0], scores[1], scores[2], _p(out7), cig, len(cig))
+    keys = ("m0s", "m0e", "m1s", "m1e", "score", "edit", "cols")
+    d = dict(zip(keys, (int(x) for x in out7)))
+    d["cigar"] = cig.value.decode()
+    return d
+
+
+class OracleRun:
+    """Result of the whole per-read path over a batch (correct.fa, discard.fa, stats, counters, walks)."""
+    COUNTERS = ("totalReadsLen", "correctedLen", "totalSeedNum", "totalWalkNum", "highErrorNum", "exceedDepthNum",
+                "exceedLeaveNum", "FMNum", "DPNum", "seedDis", "merge")
+
+    def __init__(self, o: "Oracle", h):
+        self.o, self.h = o, h
+
+    def _text(self, which):
+        n = self.o.lib.orc_run_text(self.h, which, None, 0)
+        buf = C.create_string_buffer(n + 1)
+        self.o.lib.orc_run_text(self.h, which, buf, n)
+        return buf.raw[:n].decode()
+
+    @property
+    def correct_fa(self):
+        return self._text(0)
+
+    @property
+    def discard_fa(self):
+        return self._text(1)
+
+    @property
+    def stats(self):
+        return self._text(2)
+
+    @property
+    def counters(self) -> np.ndarray:
+        n = self.o.lib.orc_run_counters(self.h, None, 0)
+        out = np.zeros(n, dtype=np.int64)
+        self.o.lib.orc_run_counters(self.h, _p(out), n)
+        return out.reshape(-1, 11)
+
+    @property
+    def walks(self) -> np.ndarray:
+        n = self.o.lib.orc_run_walks(self.h, None, 0)
+        out = np.zeros(n, dtype=np.int32)
+        self.o.lib.orc_run_walks(self.h, _p(out), n)
+        return out.reshape(-1, 5)          # read, srcStart, trgStart, code, via(0 FM, 1 DP, 2 raw/split)
+
+    @property
+    def walk_stats(self):
+        out = np.zeros(3, dtype=np.uint64)
+        self.o.lib.orc_run_walk_stats(self.h, _p(out))
+        return tuple(int(x) for x in out)  # steps, leaf expansions, refine calls
+
+    def close(self):
+        if self.h:
+            self.o.lib.orc_run_free(self.h)
+            self.h = None
 
 
 class OracleBwt:
@@ -225,6 +355,15 @@ class Ref:
         L.ref_itree_free.argtypes = [C.c_void_p]
         L.ref_itree_query.restype = C.c_uint64
         L.ref_itree_query.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64]
+
+        L.ref_extend_match.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_char_p, C.c_int]
+
+    def itree_query_all(self, start, stop, value, queries):
+        return _itree_query_all(self.lib, "ref", start, stop, value, queries)
+
+    def extend_match(self, s1: str, s2: str, start1: int, start2: int, bandwidth: int = 200, scores=(1, -1, -8)):
+        return _extend_match(self.lib.ref_extend_match, s1, s2, start1, start2, bandwidth, scores)
 
     def threshold_table(self, cov: int) -> np.ndarray:
         """One coverage per process: the reference object is an initialise-once singleton."""

@@ -100,14 +100,13 @@ uint64_t ref_itree_query(void* h, uint64_t start, uint64_t stop, uint64_t* out_v
 
 // ---- Overlapper::extendMatch -------------------------------------------------------
 // Returns the fields the DP fallback consumes (LongReadOverlap.cpp:626-659).
-int ref_extend_match(const char* s1, const char* s2, int start1, int start2, int bandwidth,
-                     int* m0s, int* m0e, int* m1s, int* m1e, int* score, int* edit,
-                     int* total_cols, char* cigar, int cigar_cap)
+int ref_extend_match(const char* s1, const char* s2, int start1, int start2, int bandwidth, int match, int gap,
+                     int mismatch, int* out7, char* cigar, int cigar_cap)
 {
-    SequenceOverlap ov = Overlapper::extendMatch(std::string(s1), std::string(s2), start1, start2, bandwidth);
-    *m0s = ov.match[0].start; *m0e = ov.match[0].end;
-    *m1s = ov.match[1].start; *m1e = ov.match[1].end;
-    *score = ov.score; *edit = ov.edit_distance; *total_cols = ov.total_columns;
+    SequenceOverlap ov = Overlapper::extendMatch(std::string(s1), std::string(s2), start1, start2, bandwidth,
+                                                 match, gap, mismatch);
+    out7[0] = ov.match[0].start; out7[1] = ov.match[0].end; out7[2] = ov.match[1].start; out7[3] = ov.match[1].end;
+    out7[4] = ov.score; out7[5] = ov.edit_distance; out7[6] = ov.total_columns;
     std::strncpy(cigar, ov.cigar.c_str(), cigar_cap - 1);
     cigar[cigar_cap - 1] = 0;
     return (int)ov.cigar.size();
