@@ -39,7 +39,7 @@ int read_bwt_file(const std::string& path, std::vector<uint8_t>& units, uint64_t
     return LRSC_OK;
 }
 
-template <class Block, class Word, unsigned kSymsPerWord>
+template <class Block>
 static int build_image_t(const uint8_t* units, uint64_t n_units, uint64_t num_symbols,
                          StrandImage& out, std::string& err)
 {
@@ -80,7 +80,8 @@ static int build_image_t(const uint8_t* units, uint64_t n_units, uint64_t num_sy
                 code = rank - 1;
                 ++counts[code];
             }
-            blk[b].bits[off / kSymsPerWord] |= (Word)code << (2 * (off % kSymsPerWord));
+            blk[b].lo[off >> 5] |= (uint32_t)(code & 1u) << (off & 31u);
+            blk[b].hi[off >> 5] |= (uint32_t)(code >> 1) << (off & 31u);
         }
     }
     if(pos != num_symbols) { err = "BWT runs do not add up to the symbol count in the header"; return LRSC_ERR_FORMAT; }
@@ -102,9 +103,9 @@ int build_strand_image(const uint8_t* units, uint64_t n_units, uint64_t num_symb
 {
     if(!wide) {
         if(num_symbols >= (1ull << 31)) { err = "Block32 layout needs < 2^31 symbols"; return LRSC_ERR_ARG; }
-        return build_image_t<Block32, uint32_t, 16>(units, n_units, num_symbols, out, err);
+        return build_image_t<Block32>(units, n_units, num_symbols, out, err);
     }
-    return build_image_t<Block64, uint64_t, 32>(units, n_units, num_symbols, out, err);
+    return build_image_t<Block64>(units, n_units, num_symbols, out, err);
 }
 
 } // namespace lrsc

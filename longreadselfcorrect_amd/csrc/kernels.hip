@@ -1,12 +1,16 @@
 // kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the FM-index hot path.
 //
 // All of these are integer rank/select over a read-only multi-GB structure: the bound is
-// HBM/L2 gather bandwidth and latency, not MFMA.  Design points:
-//   * one Occ query == one 64-byte aligned block load (4 x global_load_dwordx4 by one lane);
-//     a backward-search step issues its 4 block loads (2 strands x {lower-1, upper})
-//     back-to-back so every lane keeps 4 lines in flight, i.e. 256 lines per wavefront;
-//   * no LDS and < 128 VGPRs so that >= 16 wavefronts per CU stay resident to cover the
-//     ~2 us loaded-HBM latency (Little: ~770 lines in flight per CU saturate 6.3 TB/s);
+// gather bandwidth / latency of 64-byte blocks, not MFMA.  Design points (measured with
+// tools/gather_bench.hip: random 64-B block gathers sustain ~145 G blocks/s on this chip, so the
+// first version of this kernel at 42 G blocks/s was instruction-bound, not memory-bound):
+//   * one Occ query == one 64-byte aligned block (4 x global_load_dwordx4 by one lane); the second
+//     block of an updateInterval is only fetched when lower-1 and upper fall in different blocks;
+//   * bit-plane blocks: popcount((lo ^ L) & (hi ^ H) & mask) per 32 symbols; the partial-word masks
+//     come from a 6 KB LDS table indexed by the in-block offset (2 ds_reads instead of ~36 VALU);
+//   * 32-bit position arithmetic when the index has < 2^31 symbols (Block32), 64-bit otherwise;
+//   * the per-strand early exit of findInterval is predicated, not branched: every lane of a
+//     wavefront executes the same instruction stream for every step of the k-mer walk;
 //   * adjacent lanes own adjacent read positions: read bytes are coalesced, index blocks are
 //     inherently random (BWT order), so the 64-byte block is the unit of traffic.
 #include <hip/hip_runtime.h>
@@ -16,127 +20,206 @@
 namespace lrsc {
 
 // ---------------------------------------------------------------------------------------
-// block load + in-block rank
+// layouts
 // ---------------------------------------------------------------------------------------
 template <bool WIDE> struct Lay;
 
 template <> struct Lay<false> {
+    using pos_t = uint32_t;
     static constexpr uint32_t kSyms = Block32::kSyms;
-    struct Regs { uint4 q[4]; };   // q[0] = counts, q[1..3] = 192 symbols
+    static constexpr uint32_t kWords = Block32::kWords;
+    static constexpr uint32_t kRow = 8;                    // mask-table row stride (u32)
+    struct Regs { uint4 q[4]; };                           // q0 = counts, q1..q3 = lo[6], hi[6]
     static __device__ __forceinline__ void load(const void* blocks, uint64_t b, Regs& r)
     {
         const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const Block32*>(blocks) + b);
         r.q[0] = p[0]; r.q[1] = p[1]; r.q[2] = p[2]; r.q[3] = p[3];
     }
-    static __device__ __forceinline__ uint64_t count(const Regs& r, uint32_t code, uint32_t off, bool& flagged)
+    static __device__ __forceinline__ bool flagged(const Regs& r) { return (r.q[0].x & kFlag32) != 0; }
+    // symbols equal to `code` among the first `off` symbols of the block + the block's base count
+    static __device__ __forceinline__ uint64_t count(const Regs& r, uint32_t code, const uint32_t* __restrict__ mrow)
     {
-        const uint32_t c0 = r.q[0].x;
-        flagged = (c0 & kFlag32) != 0;
-        const uint32_t base = code == 0 ? (c0 & ~kFlag32) : code == 1 ? r.q[0].y : code == 2 ? r.q[0].z : r.q[0].w;
-        const uint32_t w[12] = {r.q[1].x, r.q[1].y, r.q[1].z, r.q[1].w, r.q[2].x, r.q[2].y,
-                                r.q[2].z, r.q[2].w, r.q[3].x, r.q[3].y, r.q[3].z, r.q[3].w};
-        return (uint64_t)base + inblock32(w, code, off);
+        const uint32_t base = code == 0 ? (r.q[0].x & ~kFlag32) : code == 1 ? r.q[0].y : code == 2 ? r.q[0].z : r.q[0].w;
+        const uint32_t L = (code & 1u) ? 0u : 0xFFFFFFFFu;
+        const uint32_t H = (code & 2u) ? 0u : 0xFFFFFFFFu;
+        const uint4 m0 = *reinterpret_cast<const uint4*>(mrow);
+        const uint2 m1 = *reinterpret_cast<const uint2*>(mrow + 4);
+        uint32_t c = base;
+        c += __builtin_popcount((r.q[1].x ^ L) & (r.q[2].z ^ H) & m0.x);
+        c += __builtin_popcount((r.q[1].y ^ L) & (r.q[2].w ^ H) & m0.y);
+        c += __builtin_popcount((r.q[1].z ^ L) & (r.q[3].x ^ H) & m0.z);
+        c += __builtin_popcount((r.q[1].w ^ L) & (r.q[3].y ^ H) & m0.w);
+        c += __builtin_popcount((r.q[2].x ^ L) & (r.q[3].z ^ H) & m1.x);
+        c += __builtin_popcount((r.q[2].y ^ L) & (r.q[3].w ^ H) & m1.y);
+        return c;
     }
     static __device__ __forceinline__ uint32_t symbol(const Regs& r, uint32_t off)
     {
-        const uint32_t w[12] = {r.q[1].x, r.q[1].y, r.q[1].z, r.q[1].w, r.q[2].x, r.q[2].y,
-                                r.q[2].z, r.q[2].w, r.q[3].x, r.q[3].y, r.q[3].z, r.q[3].w};
-        uint32_t v = 0;
+        const uint32_t lo[6] = {r.q[1].x, r.q[1].y, r.q[1].z, r.q[1].w, r.q[2].x, r.q[2].y};
+        const uint32_t hi[6] = {r.q[2].z, r.q[2].w, r.q[3].x, r.q[3].y, r.q[3].z, r.q[3].w};
+        uint32_t l = 0, h = 0;
 #pragma unroll
-        for(uint32_t i = 0; i < 12; ++i) v = (off / 16 == i) ? w[i] : v;
-        return (v >> (2 * (off % 16))) & 3u;
+        for(uint32_t i = 0; i < 6; ++i) { l = (off >> 5) == i ? lo[i] : l; h = (off >> 5) == i ? hi[i] : h; }
+        return ((l >> (off & 31u)) & 1u) | (((h >> (off & 31u)) & 1u) << 1);
     }
-    static __device__ __forceinline__ bool flagged(const Regs& r) { return (r.q[0].x & kFlag32) != 0; }
 };
 
 template <> struct Lay<true> {
+    using pos_t = uint64_t;
     static constexpr uint32_t kSyms = Block64::kSyms;
-    struct Regs { uint4 q[4]; };   // q[0..1] = counts, q[2..3] = 128 symbols
+    static constexpr uint32_t kWords = Block64::kWords;
+    static constexpr uint32_t kRow = 4;
+    struct Regs { uint4 q[4]; };                           // q0,q1 = counts, q2 = lo[4], q3 = hi[4]
     static __device__ __forceinline__ void load(const void* blocks, uint64_t b, Regs& r)
     {
         const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const Block64*>(blocks) + b);
         r.q[0] = p[0]; r.q[1] = p[1]; r.q[2] = p[2]; r.q[3] = p[3];
     }
     static __device__ __forceinline__ uint64_t u64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
-    static __device__ __forceinline__ uint64_t count(const Regs& r, uint32_t code, uint32_t off, bool& flagged)
+    static __device__ __forceinline__ bool flagged(const Regs& r) { return (r.q[0].y & 0x80000000u) != 0; }
+    static __device__ __forceinline__ uint64_t count(const Regs& r, uint32_t code, const uint32_t* __restrict__ mrow)
     {
-        const uint64_t c0 = u64(r.q[0].x, r.q[0].y);
-        flagged = (c0 & kFlag64) != 0;
-        const uint64_t base = code == 0 ? (c0 & ~kFlag64) : code == 1 ? u64(r.q[0].z, r.q[0].w)
+        const uint64_t base = code == 0 ? (u64(r.q[0].x, r.q[0].y) & ~kFlag64) : code == 1 ? u64(r.q[0].z, r.q[0].w)
                             : code == 2 ? u64(r.q[1].x, r.q[1].y) : u64(r.q[1].z, r.q[1].w);
-        const uint64_t w[4] = {u64(r.q[2].x, r.q[2].y), u64(r.q[2].z, r.q[2].w),
-                               u64(r.q[3].x, r.q[3].y), u64(r.q[3].z, r.q[3].w)};
-        return base + inblock64(w, code, off);
+        const uint32_t L = (code & 1u) ? 0u : 0xFFFFFFFFu;
+        const uint32_t H = (code & 2u) ? 0u : 0xFFFFFFFFu;
+        const uint4 m0 = *reinterpret_cast<const uint4*>(mrow);
+        uint32_t c = 0;
+        c += __builtin_popcount((r.q[2].x ^ L) & (r.q[3].x ^ H) & m0.x);
+        c += __builtin_popcount((r.q[2].y ^ L) & (r.q[3].y ^ H) & m0.y);
+        c += __builtin_popcount((r.q[2].z ^ L) & (r.q[3].z ^ H) & m0.z);
+        c += __builtin_popcount((r.q[2].w ^ L) & (r.q[3].w ^ H) & m0.w);
+        return base + c;
     }
     static __device__ __forceinline__ uint32_t symbol(const Regs& r, uint32_t off)
     {
-        const uint64_t w[4] = {u64(r.q[2].x, r.q[2].y), u64(r.q[2].z, r.q[2].w),
-                               u64(r.q[3].x, r.q[3].y), u64(r.q[3].z, r.q[3].w)};
-        uint64_t v = 0;
+        const uint32_t lo[4] = {r.q[2].x, r.q[2].y, r.q[2].z, r.q[2].w};
+        const uint32_t hi[4] = {r.q[3].x, r.q[3].y, r.q[3].z, r.q[3].w};
+        uint32_t l = 0, h = 0;
 #pragma unroll
-        for(uint32_t i = 0; i < 4; ++i) v = (off / 32 == i) ? w[i] : v;
-        return (uint32_t)(v >> (2 * (off % 32))) & 3u;
+        for(uint32_t i = 0; i < 4; ++i) { l = (off >> 5) == i ? lo[i] : l; h = (off >> 5) == i ? hi[i] : h; }
+        return ((l >> (off & 31u)) & 1u) | (((h >> (off & 31u)) & 1u) << 1);
     }
-    static __device__ __forceinline__ bool flagged(const Regs& r) { return (u64(r.q[0].x, r.q[0].y) & kFlag64) != 0; }
 };
 
-__device__ __forceinline__ uint64_t pred_of(const FmStrand& s, uint32_t code)
+// LDS table: row `off` holds the kWords partial-word masks for "the first off symbols of a block"
+template <bool WIDE>
+__device__ __forceinline__ void init_mask_table(uint32_t* tab)
 {
-    return code == 0 ? s.pred[1] : code == 1 ? s.pred[2] : code == 2 ? s.pred[3] : s.pred[4];
+    using L = Lay<WIDE>;
+    for(uint32_t i = threadIdx.x; i < (L::kSyms + 1) * L::kRow; i += blockDim.x) {
+        const uint32_t off = i / L::kRow, w = i % L::kRow;
+        tab[i] = w < L::kWords ? low_mask((int32_t)off - 32 * (int32_t)w) : 0u;
+    }
+    __syncthreads();
+}
+template <bool WIDE> struct MaskTabSize { static constexpr uint32_t value = (Lay<WIDE>::kSyms + 1) * Lay<WIDE>::kRow; };
+
+// Per-strand constants as plain scalars (wave-uniform, live in SGPRs).  Built from the kernel
+// argument with constant member indices only: indexing the by-value argument struct dynamically
+// makes the compiler copy it to scratch.
+template <class P>
+struct StrandC {
+    const void* blocks;
+    const uint64_t* dollars;
+    uint64_t n_dollars;
+    P c1, c2, c3, c4, n;      // C[A], C[C], C[G], C[T], N
+};
+template <class P>
+__device__ __forceinline__ StrandC<P> strand_consts(const FmStrand& s)
+{
+    StrandC<P> c;
+    c.blocks = s.blocks; c.dollars = s.dollars; c.n_dollars = s.n_dollars;
+    c.c1 = (P)s.pred[1]; c.c2 = (P)s.pred[2]; c.c3 = (P)s.pred[3]; c.c4 = (P)s.pred[4]; c.n = (P)s.n_symbols;
+    return c;
+}
+// C[code + 1] without a table: three predicated adds of uniform deltas
+template <class P>
+__device__ __forceinline__ P pred_of(const StrandC<P>& s, uint32_t code)
+{
+    P v = s.c1;
+    v += code >= 1 ? (s.c2 - s.c1) : 0;
+    v += code >= 2 ? (s.c3 - s.c2) : 0;
+    v += code >= 3 ? (s.c4 - s.c3) : 0;
+    return v;
+}
+// C[code + 2] (or N for T): upper end of the single-symbol interval
+template <class P>
+__device__ __forceinline__ P pred_next(const StrandC<P>& s, uint32_t code)
+{
+    P v = s.c2;
+    v += code >= 1 ? (s.c3 - s.c2) : 0;
+    v += code >= 2 ? (s.c4 - s.c3) : 0;
+    v += code >= 3 ? (s.n - s.c4) : 0;
+    return v;
+}
+template <class P>
+__device__ __forceinline__ uint64_t dollars_in_c(const StrandC<P>& s, uint64_t lo, uint64_t hi)
+{
+    uint64_t a = 0, b = s.n_dollars;
+    while(a < b) { const uint64_t m = (a + b) >> 1; if(s.dollars[m] < lo) a = m + 1; else b = m; }
+    const uint64_t first = a;
+    b = s.n_dollars;
+    while(a < b) { const uint64_t m = (a + b) >> 1; if(s.dollars[m] < hi) a = m + 1; else b = m; }
+    return a - first;
 }
 
 // Occ over the first p symbols (p = idx + 1, 0 <= p <= N): RLBWT::getOcc (RLBWT.h:121-140)
 template <bool WIDE>
-__device__ __forceinline__ uint64_t occ_prefix(const FmStrand& s, uint32_t code, uint64_t p)
+__device__ __forceinline__ uint64_t occ_prefix(const StrandC<typename Lay<WIDE>::pos_t>& s, uint32_t code,
+                                               typename Lay<WIDE>::pos_t p, const uint32_t* __restrict__ mtab)
 {
     using L = Lay<WIDE>;
-    const uint64_t b = p / L::kSyms;
+    const typename L::pos_t b = p / L::kSyms;
     const uint32_t off = (uint32_t)(p - b * L::kSyms);
     typename L::Regs r;
     L::load(s.blocks, b, r);
-    bool flagged;
-    uint64_t c = L::count(r, code, off, flagged);
-    if(code == 0 && flagged && off != 0) c -= dollars_in(s, b * L::kSyms, b * L::kSyms + off);
+    uint64_t c = L::count(r, code, mtab + off * L::kRow);
+    if(code == 0 && off != 0 && L::flagged(r)) c -= dollars_in_c(s, (uint64_t)b * L::kSyms, (uint64_t)b * L::kSyms + off);
     return c;
 }
 
-struct Iv { int64_t lo, hi; };
+template <class P> struct IvT { P lo, hi; };   // lower, upper; upper stored as-is (>= 0 always: pred >= 1)
 
-// BWTAlgorithms::updateInterval (BWTAlgorithms.h:66-72) on one strand.
-// Both block loads are issued before either is consumed.
+// BWTAlgorithms::updateInterval (BWTAlgorithms.h:66-72) on one strand.  The second block is only
+// loaded when the two rank positions straddle a block boundary.
 template <bool WIDE>
-__device__ __forceinline__ void update_interval(const FmStrand& s, uint32_t code, Iv& iv,
-                                                uint32_t& n_rank, uint32_t& n_blk)
+__device__ __forceinline__ IvT<typename Lay<WIDE>::pos_t> update_interval(const StrandC<typename Lay<WIDE>::pos_t>& s, uint32_t code,
+                                                                          IvT<typename Lay<WIDE>::pos_t> iv,
+                                                                          const uint32_t* __restrict__ mtab, uint32_t& n_blk)
 {
     using L = Lay<WIDE>;
-    const uint64_t pl = (uint64_t)iv.lo;            // (lower - 1) + 1
-    const uint64_t pu = (uint64_t)iv.hi + 1;        // upper + 1
-    const uint64_t bl = pl / L::kSyms, bu = pu / L::kSyms;
+    using P = typename L::pos_t;
+    const P pl = iv.lo;            // (lower - 1) + 1
+    const P pu = iv.hi + 1;        // upper + 1
+    const P bl = pl / L::kSyms, bu = pu / L::kSyms;
     const uint32_t ol = (uint32_t)(pl - bl * L::kSyms), ou = (uint32_t)(pu - bu * L::kSyms);
     typename L::Regs ra, rb;
     L::load(s.blocks, bl, ra);
-    L::load(s.blocks, bu, rb);
-    bool fa, fb;
-    uint64_t ca = L::count(ra, code, ol, fa);
-    uint64_t cb = L::count(rb, code, ou, fb);
+    rb = ra;
+    if(bu != bl) L::load(s.blocks, bu, rb);
+    uint64_t ca = L::count(ra, code, mtab + ol * L::kRow);
+    uint64_t cb = L::count(rb, code, mtab + ou * L::kRow);
     if(code == 0) {
-        if(fa && ol != 0) ca -= dollars_in(s, bl * L::kSyms, bl * L::kSyms + ol);
-        if(fb && ou != 0) cb -= dollars_in(s, bu * L::kSyms, bu * L::kSyms + ou);
+        if(ol != 0 && L::flagged(ra)) ca -= dollars_in_c(s, (uint64_t)bl * L::kSyms, (uint64_t)bl * L::kSyms + ol);
+        if(ou != 0 && L::flagged(rb)) cb -= dollars_in_c(s, (uint64_t)bu * L::kSyms, (uint64_t)bu * L::kSyms + ou);
     }
-    const uint64_t pb = pred_of(s, code);
-    iv.lo = (int64_t)(pb + ca);
-    iv.hi = (int64_t)(pb + cb) - 1;
-    n_rank += 2;
+    const P pb = pred_of(s, code);
+    IvT<P> out;
+    out.lo = pb + (P)ca;
+    out.hi = pb + (P)cb - 1;
     n_blk += (bl == bu) ? 1u : 2u;
+    return out;
 }
 
 // BWTAlgorithms::initInterval (BWTAlgorithms.h:136-140): Occ(b, N-1) is the symbol total.
-__device__ __forceinline__ void init_interval(const FmStrand& s, uint32_t code, Iv& iv)
+template <class P>
+__device__ __forceinline__ IvT<P> init_interval(const StrandC<P>& s, uint32_t code)
 {
-    const uint64_t lo = pred_of(s, code);
-    const uint64_t next = code == 3 ? s.n_symbols : pred_of(s, code + 1);
-    iv.lo = (int64_t)lo;
-    iv.hi = (int64_t)next - 1;
+    IvT<P> iv;
+    iv.lo = pred_of(s, code);
+    iv.hi = pred_next(s, code) - 1;
+    return iv;
 }
 
 __device__ __forceinline__ void flush_counters(DevCounters* ctr, uint32_t n_rank, uint32_t n_blk)
@@ -160,45 +243,69 @@ __device__ __forceinline__ void flush_counters(DevCounters* ctr, uint32_t n_rank
 // A lane owns one start position and steps left-to-right through the read: the fwd interval
 // is the backward search of reverse(w) in the rbwt, the rvc interval the backward search of
 // revcomp(w) in the bwt, so both consume w[0], w[1], ... in order (BWTAlgorithms.cpp:32-38).
-// Steps < base_k reproduce findInterval's early exit per strand (BWTAlgorithms.cpp:28);
-// steps >= base_k are KmerFeature::expand (KmerFeature.h:92-99): no validity check.
+// Steps < base_k reproduce findInterval's early exit per strand (BWTAlgorithms.cpp:28): a strand
+// that went invalid keeps its interval until step base_k; steps >= base_k are
+// KmerFeature::expand (KmerFeature.h:92-99): always applied, no validity check.
 // ---------------------------------------------------------------------------------------
+template <class P>
 struct WalkState {
-    Iv fwd, rvc;
+    IvT<P> fwd, rvc;
     uint32_t size;          // bases consumed
     uint32_t counted;       // bases counted by the base search (fwd strand)
+    uint32_t n_rank, n_blk; // accounting: Occ queries issued / rank blocks needed
     bool fwd_broken, rvc_broken;
 };
+template <class P>
+__device__ __forceinline__ WalkState<P> walk_init()
+{
+    WalkState<P> st;
+    st.size = 0; st.counted = 0; st.n_rank = 0; st.n_blk = 0; st.fwd_broken = false; st.rvc_broken = false;
+    st.fwd.lo = st.fwd.hi = st.rvc.lo = st.rvc.hi = 0;
+    return st;
+}
 
 template <bool WIDE>
-__device__ __forceinline__ void walk_step(const FmIndexDev& fm, uint32_t c, uint32_t base_k, WalkState& st,
-                                          uint32_t& n_rank, uint32_t& n_blk)
+__device__ __forceinline__ WalkState<typename Lay<WIDE>::pos_t>
+walk_step(const StrandC<typename Lay<WIDE>::pos_t>& sf, const StrandC<typename Lay<WIDE>::pos_t>& sr, uint32_t c,
+          uint32_t base_k, WalkState<typename Lay<WIDE>::pos_t> st, const uint32_t* __restrict__ mtab)
 {
-    const FmStrand& sf = fm.strand[LRSC_RBWT];
-    const FmStrand& sr = fm.strand[LRSC_BWT];
+    using P = typename Lay<WIDE>::pos_t;
     if(st.size == 0) {
-        init_interval(sf, c, st.fwd);
-        init_interval(sr, 3u - c, st.rvc);
+        st.fwd = init_interval<P>(sf, c);
+        st.rvc = init_interval<P>(sr, 3u - c);
         st.counted = 1;
-        n_rank += 2;   // initInterval's getOcc(b, N-1) per strand (served from pred[] here)
-    } else if(st.size >= base_k) {
-        update_interval<WIDE>(sf, c, st.fwd, n_rank, n_blk);
-        update_interval<WIDE>(sr, 3u - c, st.rvc, n_rank, n_blk);
+        st.n_rank += 2;   // initInterval's getOcc(b, N-1) per strand (served from C[] here)
     } else {
-        if(!st.fwd_broken) {
-            ++st.counted;
-            update_interval<WIDE>(sf, c, st.fwd, n_rank, n_blk);
-            st.fwd_broken = st.fwd.lo > st.fwd.hi;
+        const bool in_base = st.size < base_k;
+        const bool do_f = !(in_base && st.fwd_broken);
+        const bool do_r = !(in_base && st.rvc_broken);
+        uint32_t bf = 0, br = 0;
+        const IvT<P> nf = update_interval<WIDE>(sf, c, st.fwd, mtab, bf);
+        const IvT<P> nr = update_interval<WIDE>(sr, 3u - c, st.rvc, mtab, br);
+        if(do_f) {
+            st.fwd = nf;
+            st.counted += in_base ? 1u : 0u;
+            st.fwd_broken = in_base && (nf.lo > nf.hi);
+            st.n_rank += 2; st.n_blk += bf;
         }
-        if(!st.rvc_broken) {
-            update_interval<WIDE>(sr, 3u - c, st.rvc, n_rank, n_blk);
-            st.rvc_broken = st.rvc.lo > st.rvc.hi;
+        if(do_r) {
+            st.rvc = nr;
+            st.rvc_broken = in_base && (nr.lo > nr.hi);
+            st.n_rank += 2; st.n_blk += br;
         }
     }
     ++st.size;
+    return st;
 }
 
-__device__ __forceinline__ int64_t iv_freq(const Iv& iv) { return iv.lo <= iv.hi ? iv.hi - iv.lo + 1 : 0; }
+template <class P> __device__ __forceinline__ int64_t iv_freq(const IvT<P>& iv) { return iv.lo <= iv.hi ? (int64_t)(iv.hi - iv.lo) + 1 : 0; }
+template <class P> __device__ __forceinline__ lrsc_biinterval to_out(const IvT<P>& f, const IvT<P>& r)
+{
+    lrsc_biinterval o;
+    o.fwd.lower = (int64_t)f.lo; o.fwd.upper = (int64_t)f.hi;
+    o.rvc.lower = (int64_t)r.lo; o.rvc.upper = (int64_t)r.hi;
+    return o;
+}
 
 // ---------------------------------------------------------------------------------------
 // kernels
@@ -207,12 +314,19 @@ template <bool WIDE>
 __global__ __launch_bounds__(256) void rank_kernel(FmIndexDev fm, const lrsc_rank_query* __restrict__ q,
                                                    uint64_t n, uint64_t* __restrict__ out, DevCounters* ctr)
 {
+    __shared__ __attribute__((aligned(16))) uint32_t mtab[MaskTabSize<WIDE>::value];
+    init_mask_table<WIDE>(mtab);
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     uint32_t n_rank = 0, n_blk = 0;
     if(i < n) {
         const lrsc_rank_query qq = q[i];
         const uint32_t code = ((qq.base >> 1) & 3u) ^ (((qq.base >> 1) & 3u) >> 1);
-        out[i] = occ_prefix<WIDE>(fm.strand[qq.strand & 1], code, (uint64_t)(qq.idx + 1));
+        using P = typename Lay<WIDE>::pos_t;
+        const StrandC<P> s0 = strand_consts<P>(fm.strand[0]);
+        const StrandC<P> s1 = strand_consts<P>(fm.strand[1]);
+        const uint64_t r0 = occ_prefix<WIDE>(s0, code, (P)(qq.idx + 1), mtab);
+        const uint64_t r1 = occ_prefix<WIDE>(s1, code, (P)(qq.idx + 1), mtab);
+        out[i] = (qq.strand & 1) ? r1 : r0;
         n_rank = 1; n_blk = 1;
     }
     flush_counters(ctr, n_rank, n_blk);
@@ -225,7 +339,7 @@ __global__ __launch_bounds__(256) void bwt_chars_kernel(FmIndexDev fm, int stran
     using L = Lay<WIDE>;
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if(i >= n) return;
-    const FmStrand& s = fm.strand[strand & 1];
+    const StrandC<uint64_t> s = (strand & 1) ? strand_consts<uint64_t>(fm.strand[1]) : strand_consts<uint64_t>(fm.strand[0]);
     const uint64_t p = idx[i];
     const uint64_t b = p / L::kSyms;
     const uint32_t off = (uint32_t)(p - b * L::kSyms);
@@ -233,7 +347,7 @@ __global__ __launch_bounds__(256) void bwt_chars_kernel(FmIndexDev fm, int stran
     L::load(s.blocks, b, r);
     const uint32_t code = L::symbol(r, off);
     char ch = "ACGT"[code];
-    if(code == 0 && L::flagged(r) && dollars_in(s, p, p + 1) != 0) ch = '$';
+    if(code == 0 && L::flagged(r) && dollars_in_c(s, p, p + 1) != 0) ch = '$';
     out[i] = ch;
 }
 
@@ -241,21 +355,22 @@ template <bool WIDE>
 __global__ __launch_bounds__(256) void find_kmers_kernel(FmIndexDev fm, const uint8_t* __restrict__ codes, uint32_t k,
                                                          uint64_t n, lrsc_biinterval* __restrict__ out, DevCounters* ctr)
 {
+    using P = typename Lay<WIDE>::pos_t;
+    __shared__ __attribute__((aligned(16))) uint32_t mtab[MaskTabSize<WIDE>::value];
+    init_mask_table<WIDE>(mtab);
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     uint32_t n_rank = 0, n_blk = 0;
     if(i < n) {
-        WalkState st;
-        st.size = 0; st.counted = 0; st.fwd_broken = false; st.rvc_broken = false;
-        st.fwd.lo = st.fwd.hi = st.rvc.lo = st.rvc.hi = 0;
+        const StrandC<P> sf = strand_consts<P>(fm.strand[LRSC_RBWT]);
+        const StrandC<P> sr = strand_consts<P>(fm.strand[LRSC_BWT]);
+        WalkState<P> st = walk_init<P>();
         const uint8_t* w = codes + i * k;
         for(uint32_t s = 0; s < k; ++s) {
             if(st.fwd_broken && st.rvc_broken) break;
-            walk_step<WIDE>(fm, w[s], k, st, n_rank, n_blk);
+            st = walk_step<WIDE>(sf, sr, w[s], k, st, mtab);
         }
-        lrsc_biinterval o;
-        o.fwd.lower = st.fwd.lo; o.fwd.upper = st.fwd.hi;
-        o.rvc.lower = st.rvc.lo; o.rvc.upper = st.rvc.hi;
-        out[i] = o;
+        out[i] = to_out(st.fwd, st.rvc);
+        n_rank = st.n_rank; n_blk = st.n_blk;
     }
     flush_counters(ctr, n_rank, n_blk);
 }
@@ -263,6 +378,9 @@ __global__ __launch_bounds__(256) void find_kmers_kernel(FmIndexDev fm, const ui
 template <bool WIDE>
 __global__ __launch_bounds__(256) void kmer_grid_kernel(FmIndexDev fm, GridArgs a, DevCounters* ctr)
 {
+    using P = typename Lay<WIDE>::pos_t;
+    __shared__ __attribute__((aligned(16))) uint32_t mtab[MaskTabSize<WIDE>::value];
+    init_mask_table<WIDE>(mtab);
     const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     uint32_t n_rank = 0, n_blk = 0;
     if(gid < a.total_bases) {
@@ -275,20 +393,16 @@ __global__ __launch_bounds__(256) void kmer_grid_kernel(FmIndexDev fm, GridArgs 
         const uint64_t remain64 = end - gid;
         const uint32_t avail = remain64 < kmax ? (uint32_t)remain64 : kmax;
 
-        WalkState st;
-        st.size = 0; st.counted = 0; st.fwd_broken = false; st.rvc_broken = false;
-        st.fwd.lo = st.fwd.hi = st.rvc.lo = st.rvc.hi = 0;
+        const StrandC<P> sf = strand_consts<P>(fm.strand[LRSC_RBWT]);
+        const StrandC<P> sr = strand_consts<P>(fm.strand[LRSC_BWT]);
+        WalkState<P> st = walk_init<P>();
         uint32_t slot = 0;
+        uint32_t next_k = a.ks[0];
         const uint8_t* w = a.codes + gid;
 
         auto emit = [&](uint32_t j) {
             const uint64_t rec = gid * a.n_k + j;
-            if(a.out_iv) {
-                lrsc_biinterval o;
-                o.fwd.lower = st.fwd.lo; o.fwd.upper = st.fwd.hi;
-                o.rvc.lower = st.rvc.lo; o.rvc.upper = st.rvc.hi;
-                a.out_iv[rec] = o;
-            }
+            if(a.out_iv) a.out_iv[rec] = to_out(st.fwd, st.rvc);
             if(a.out_size) a.out_size[rec] = (uint8_t)st.size;
             if(a.out_count) {
                 // composition of the counted bases: w[0..counted) from the base search, then
@@ -301,28 +415,28 @@ __global__ __launch_bounds__(256) void kmer_grid_kernel(FmIndexDev fm, GridArgs 
                         cnt[0] += (c == 0); cnt[1] += (c == 1); cnt[2] += (c == 2); cnt[3] += (c == 3);
                     }
                 }
-                uchar4 v = make_uchar4((uint8_t)cnt[0], (uint8_t)cnt[1], (uint8_t)cnt[2], (uint8_t)cnt[3]);
-                reinterpret_cast<uchar4*>(a.out_count)[rec] = v;
+                reinterpret_cast<uchar4*>(a.out_count)[rec] =
+                    make_uchar4((uint8_t)cnt[0], (uint8_t)cnt[1], (uint8_t)cnt[2], (uint8_t)cnt[3]);
             }
             if(a.freq) {
                 const bool fake = st.size != a.ks[j];
                 a.freq[(uint64_t)j * a.total_bases + gid] = fake ? -1 : (int32_t)(iv_freq(st.fwd) + iv_freq(st.rvc));
             }
-            if(a.slot_iv) {
-                lrsc_biinterval o;
-                o.fwd.lower = st.fwd.lo; o.fwd.upper = st.fwd.hi;
-                o.rvc.lower = st.rvc.lo; o.rvc.upper = st.rvc.hi;
-                a.slot_iv[(uint64_t)j * a.total_bases + gid] = o;
-            }
+            if(a.slot_iv) a.slot_iv[(uint64_t)j * a.total_bases + gid] = to_out(st.fwd, st.rvc);
         };
 
         for(uint32_t s = 0; s < avail; ++s) {
-            walk_step<WIDE>(fm, w[s], base_k, st, n_rank, n_blk);
-            if(st.size == a.ks[slot]) { emit(slot); ++slot; }
+            st = walk_step<WIDE>(sf, sr, w[s], base_k, st, mtab);
+            if(st.size == next_k) {
+                emit(slot);
+                ++slot;
+                next_k = slot < a.n_k ? a.ks[slot] : 0xFFFFFFFFu;
+            }
         }
         // slots the read end cut short keep the last state ("fake" k-mers, KmerFeature.h:62)
         for(; slot < a.n_k; ++slot) emit(slot);
         if(a.base_counted) a.base_counted[gid] = (uint8_t)st.counted;
+        n_rank = st.n_rank; n_blk = st.n_blk;
     }
     flush_counters(ctr, n_rank, n_blk);
 }
