@@ -166,6 +166,33 @@ void lrsc_batch_destroy(lrsc_batch* b);
  * (compact per-position features only).  Timed internally with HIP events on the ctx stream. */
 int lrsc_batch_kmer_grid(lrsc_ctx* ctx, lrsc_batch* b);
 
+/* ---- LongReadProbe seeds ------------------------------------------------------------------ */
+/* SeedFeature (PacBio/SeedFeature.h:35-45) as searchSeedsWithHybridKmers leaves it, i.e. after
+ * estimateBestKmerSize and removeHitchhikingSeeds.  seedStr == read[start, start+len). */
+typedef struct lrsc_seed {
+    int32_t start;                /* seedStartPos (seedEndPos = start + len - 1) */
+    int32_t len;                  /* seedLen                                      */
+    int32_t max_fixed_mer_freq;   /* maxFixedMerFreq                              */
+    int32_t is_repeat;            /* isRepeat                                     */
+    int32_t start_best_kmer_size; /* startBestKmerSize                            */
+    int32_t end_best_kmer_size;   /* endBestKmerSize                              */
+    int32_t start_kmer_freq;      /* startKmerFreq                                */
+    int32_t end_kmer_freq;        /* endKmerFreq                                  */
+} lrsc_seed;
+/* KmerThreshold table (PacBio/KmerThreshold.cpp:43-79) for `coverage`: out[mode*52 + k], mode 0..2, k 0..51. */
+int lrsc_kmer_thresholds(int coverage, float* out);
+/* Seeds of every read of a resident batch: k-mer grid, LongReadProbe::getSeqAttribute,
+ * searchSeedsWithHybridKmers (PacBio/LongReadProbe.cpp:34-227), all on the device. */
+int lrsc_batch_find_seeds(lrsc_ctx* ctx, lrsc_batch* b);
+/* Copy the result of lrsc_batch_find_seeds to the host: seed_count[n_reads]; seeds (read order, then
+ * position order; may be NULL) with capacity `cap` records; *n_seeds = total; attribute (optional) one
+ * byte per base: 1 unique, 2 repeat (getSeqAttribute). LRSC_ERR_CAPACITY if cap is too small. */
+int lrsc_batch_seeds(lrsc_ctx* ctx, lrsc_batch* b, uint32_t* seed_count, lrsc_seed* seeds, uint64_t cap,
+                     uint64_t* n_seeds, int8_t* attribute);
+/* Convenience: upload, find, fetch, release. */
+int lrsc_find_seeds(lrsc_ctx* ctx, const char* reads, const uint64_t* read_off, uint32_t n_reads,
+                    uint32_t* seed_count, lrsc_seed* seeds, uint64_t cap, uint64_t* n_seeds, int8_t* attribute);
+
 /* ---- measurement ------------------------------------------------------------------------- */
 typedef struct lrsc_kernel_stats {
     uint64_t launches;          /* launches since the last reset                        */

@@ -82,6 +82,8 @@ class KernelStats(C.Structure):
 
 
 K_RANK, K_FIND, K_GRID, K_SEEDS, K_EXTEND = range(5)
+SEED_DTYPE = np.dtype([("start", "<i4"), ("len", "<i4"), ("max_freq", "<i4"), ("repeat", "<i4"), ("start_k", "<i4"),
+                       ("end_k", "<i4"), ("start_freq", "<i4"), ("end_freq", "<i4")])
 BWT, RBWT = 0, 1
 
 RANK_DTYPE = np.dtype([("idx", "<i8"), ("base", "u1"), ("strand", "u1"), ("pad", "u1", (6,))])
@@ -143,6 +145,12 @@ class Lrsc:
         L.lrsc_batch_destroy.argtypes = [C.c_void_p]
         L.lrsc_batch_destroy.restype = None
         L.lrsc_batch_kmer_grid.argtypes = [C.c_void_p, C.c_void_p]
+        L.lrsc_kmer_thresholds.argtypes = [C.c_int, C.c_void_p]
+        L.lrsc_batch_find_seeds.argtypes = [C.c_void_p, C.c_void_p]
+        L.lrsc_batch_seeds.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
+                                       C.c_void_p]
+        L.lrsc_find_seeds.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64,
+                                      C.POINTER(C.c_uint64), C.c_void_p]
         L.lrsc_ctx_stats.argtypes = [C.c_void_p, C.c_int, C.POINTER(KernelStats)]
         L.lrsc_ctx_stats_reset.argtypes = [C.c_void_p]
         L.lrsc_synth_genome.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p]
@@ -158,6 +166,11 @@ class Lrsc:
         p = Params()
         self.check(self.lib.lrsc_params_default(genome, coverage, C.byref(p)), "lrsc_params_default")
         return p
+
+    def kmer_thresholds(self, coverage: int) -> np.ndarray:
+        out = np.zeros((3, 52), dtype=np.float32)
+        self.check(self.lib.lrsc_kmer_thresholds(coverage, _ptr(out)), "lrsc_kmer_thresholds")
+        return out
 
     # ---- synthetic data -------------------------------------------------------------------
     def synth_genome(self, seed: int, length: int) -> np.ndarray:
@@ -316,6 +329,26 @@ class Batch:
 
     def kmer_grid(self):
         self.ctx.api.check(self.ctx.api.lib.lrsc_batch_kmer_grid(self.ctx.h, self.h), "lrsc_batch_kmer_grid")
+
+    def find_seeds(self):
+        self.ctx.api.check(self.ctx.api.lib.lrsc_batch_find_seeds(self.ctx.h, self.h), "lrsc_batch_find_seeds")
+
+    def seeds(self, want_attribute: bool = True):
+        """-> (seed_count uint32[n_reads], seeds SEED_DTYPE[n], attribute int8[total] | None)."""
+        api = self.ctx.api
+        count = np.zeros(self.n_reads, dtype=np.uint32)
+        n = C.c_uint64()
+        attr = np.zeros(self.total_bases, dtype=np.int8) if want_attribute else None
+        cap = max(1024, self.total_bases // 8)
+        while True:
+            seeds = np.zeros(cap, dtype=SEED_DTYPE)
+            st = api.lib.lrsc_batch_seeds(self.ctx.h, self.h, _ptr(count), _ptr(seeds), cap, C.byref(n),
+                                          _ptr(attr) if attr is not None else None)
+            if st == -6:
+                cap = int(n.value)
+                continue
+            api.check(st, "lrsc_batch_seeds")
+            return count, seeds[: n.value].copy(), attr
 
     def close(self):
         if self.h:

@@ -7,7 +7,9 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
+#include <limits>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -101,8 +103,25 @@ struct lrsc_batch {
     // compact grid features (resident)
     uint32_t n_k = 0;
     uint8_t ks[kMaxPool]{};
+    int8_t freq_index[kMaxPool]{};
+    int8_t row_of_k[64]{};
+    uint32_t n_rows = 0;
     int32_t* d_freq = nullptr;
     uint8_t* d_base_counted = nullptr;
+    uint8_t* d_valid = nullptr;
+    bool grid_done = false;
+    // seed finding
+    uint32_t min_k = 1;
+    uint64_t seed_cap = 0;
+    unsigned long long* d_flags = nullptr;
+    uint32_t* d_zeros = nullptr;
+    uint8_t* d_attr = nullptr;
+    int32_t* d_seeds = nullptr;
+    uint32_t* d_seed_count = nullptr;
+    float* d_thr = nullptr;
+    void* d_scan_tmp = nullptr;
+    size_t scan_tmp_cap = 0;
+    bool seeds_done = false;
 };
 
 // ---------------------------------------------------------------------------------------
@@ -575,8 +594,9 @@ extern "C" void lrsc_batch_destroy(lrsc_batch* b)
     if(b->d_codes) (void)hipFree(b->d_codes);
     if(b->d_off) (void)hipFree(b->d_off);
     if(b->d_chunk) (void)hipFree(b->d_chunk);
-    if(b->d_freq) (void)hipFree(b->d_freq);
-    if(b->d_base_counted) (void)hipFree(b->d_base_counted);
+    void* ptrs[] = {b->d_freq, b->d_base_counted, b->d_valid, b->d_flags, b->d_zeros, b->d_attr, b->d_seeds,
+                    b->d_seed_count, b->d_thr, b->d_scan_tmp};
+    for(void* q : ptrs) if(q) (void)hipFree(q);
     delete b;
 }
 
@@ -626,15 +646,63 @@ static uint32_t pool_from_params(const lrsc_params& p, uint8_t* ks)
     return n;
 }
 
-extern "C" int lrsc_batch_kmer_grid(lrsc_ctx* ctx, lrsc_batch* b)
+// KmerThreshold::initialize(-1, 50, cov) + calculate (PacBio/KmerThreshold.cpp:11-25,43-63,74-79):
+// float arithmetic left to right, floored at 2.0f, running minimum over k; entries below k = 15 and
+// k = 51 stay 0.0f.  The host computes it once; the kernels only read the table.
+static const float kThresholdFormula[3][6] = {
+    {0.0004799107143, -0.008037815126, 0.03673552754, 0.1850695903, -1.572552521, 18.0522088},
+    {0.0003348214286, -0.009112394958, 0.04286714686, 0.240519958, -1.8793367350, 21.29319228},
+    {0.01714285714, -0.6193907563, 2.266956783, 17.28450630, -100.6983493, 1103.571729}};
+
+extern "C" int lrsc_kmer_thresholds(int coverage, float* out)
 {
-    if(!ctx || !b || b->ctx != ctx) return fail(LRSC_ERR_ARG, "batch does not belong to this ctx");
-    HIP_TRY(hipSetDevice(ctx->device));
-    if(b->n_k == 0) {
-        b->n_k = pool_from_params(ctx->params, b->ks);
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_freq), (size_t)b->n_k * b->total_bases * sizeof(int32_t)));
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_base_counted), b->total_bases));
+    if(!out) return fail(LRSC_ERR_ARG, "null");
+    const int start = 15, end = 50;
+    for(int mode = 0; mode < 3; ++mode) {
+        for(int k = 0; k < 52; ++k) out[mode * 52 + k] = 0.0f;
+        float cavity = std::numeric_limits<float>::max();
+        const float* f = kThresholdFormula[mode];
+        const int x = coverage;
+        for(int y = start; y <= end; ++y) {
+            float v = f[0] * x * x + f[1] * x * y + f[2] * y * y + f[3] * x + f[4] * y + f[5];
+            v = std::fmax(v, 2.0f);
+            cavity = std::fmin(cavity, v);
+            out[mode * 52 + y] = cavity;
+        }
     }
+    return LRSC_OK;
+}
+
+static int batch_setup_rows(lrsc_ctx* ctx, lrsc_batch* b)
+{
+    if(b->n_k != 0) return LRSC_OK;
+    const lrsc_params& p = ctx->params;
+    b->n_k = pool_from_params(p, b->ks);
+    for(auto& x : b->row_of_k) x = -1;
+    for(auto& x : b->freq_index) x = -1;
+    // rows kept resident: the scan k-mer and the three static k-mer sizes (LongReadProbe.cpp:49,61,141)
+    int wanted[4] = {p.scan_kmer_len, p.start_kmer_len + p.offset[0], p.start_kmer_len + p.offset[1],
+                     p.start_kmer_len + p.offset[2]};
+    int min_k = 1 << 30;
+    for(int i = 0; i < 4; ++i) {
+        const int k = wanted[i];
+        if(k <= 0 || k > 51) return fail(LRSC_ERR_ARG, "k-mer sizes must lie in 1..51");
+        if(i > 0 && k < min_k) min_k = k;
+        if(b->row_of_k[k] >= 0) continue;
+        for(uint32_t j = 0; j < b->n_k; ++j)
+            if(b->ks[j] == k) { b->freq_index[j] = (int8_t)b->n_rows; b->row_of_k[k] = (int8_t)b->n_rows; ++b->n_rows; }
+        if(b->row_of_k[k] < 0) return fail(LRSC_ERR_ARG, "k-mer size missing from the pool");
+    }
+    b->min_k = (uint32_t)min_k;
+    if(b->total_bases >= (1ull << 32)) return fail(LRSC_ERR_UNSUPPORTED, "a resident batch holds < 2^32 bases");
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_freq), (size_t)b->n_rows * b->total_bases * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_base_counted), b->total_bases));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_valid), b->total_bases));
+    return LRSC_OK;
+}
+
+static GridArgs batch_grid_args(const lrsc_batch* b)
+{
     GridArgs a{};
     a.codes = b->d_codes;
     a.read_off = b->d_off;
@@ -642,8 +710,118 @@ extern "C" int lrsc_batch_kmer_grid(lrsc_ctx* ctx, lrsc_batch* b)
     a.total_bases = b->total_bases;
     a.n_reads = b->n_reads;
     a.n_k = b->n_k;
-    for(uint32_t i = 0; i < b->n_k; ++i) a.ks[i] = b->ks[i];
+    for(uint32_t i = 0; i < b->n_k; ++i) { a.ks[i] = b->ks[i]; a.freq_index[i] = b->freq_index[i]; }
     a.freq = b->d_freq;
     a.base_counted = b->d_base_counted;
-    return timed_launch(ctx, LRSC_K_GRID, [&]() { return launch_kmer_grid(ctx->fm, a, ctx->d_ctr, ctx->stream); });
+    a.valid_mask = b->d_valid;
+    return a;
+}
+
+extern "C" int lrsc_batch_kmer_grid(lrsc_ctx* ctx, lrsc_batch* b)
+{
+    if(!ctx || !b || b->ctx != ctx) return fail(LRSC_ERR_ARG, "batch does not belong to this ctx");
+    HIP_TRY(hipSetDevice(ctx->device));
+    int st = batch_setup_rows(ctx, b);
+    if(st != LRSC_OK) return st;
+    const GridArgs a = batch_grid_args(b);
+    st = timed_launch(ctx, LRSC_K_GRID, [&]() { return launch_kmer_grid(ctx->fm, a, ctx->d_ctr, ctx->stream); });
+    if(st == LRSC_OK) b->grid_done = true;
+    return st;
+}
+
+static int batch_setup_seeds(lrsc_ctx* ctx, lrsc_batch* b)
+{
+    if(b->d_seeds) return LRSC_OK;
+    b->seed_cap = b->total_bases / b->min_k + b->n_reads + 1;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_flags), b->total_bases * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_zeros), b->total_bases * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_attr), b->total_bases));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_seeds), b->seed_cap * kSeedInts * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_seed_count), (size_t)b->n_reads * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_thr), 3 * 52 * sizeof(float)));
+    float thr[3 * 52];
+    (void)lrsc_kmer_thresholds(ctx->params.pb_coverage, thr);
+    HIP_TRY(hipMemcpy(b->d_thr, thr, sizeof(thr), hipMemcpyHostToDevice));
+    return LRSC_OK;
+}
+
+static SeedArgs batch_seed_args(const lrsc_ctx* ctx, const lrsc_batch* b)
+{
+    const lrsc_params& p = ctx->params;
+    SeedArgs a{};
+    a.codes = b->d_codes; a.read_off = b->d_off; a.chunk_read = b->d_chunk;
+    a.total_bases = b->total_bases; a.n_reads = b->n_reads;
+    a.freq = b->d_freq; a.valid_mask = b->d_valid; a.base_counted = b->d_base_counted;
+    for(int i = 0; i < 64; ++i) a.row_of_k[i] = b->row_of_k[i];
+    a.base_k = b->ks[0];
+    a.start_kmer_len = p.start_kmer_len; a.scan_kmer_len = p.scan_kmer_len; a.kmer_len_up_bound = p.kmer_len_up_bound;
+    a.pb_coverage = p.pb_coverage; a.mode = p.mode; a.manual = p.manual; a.radius = p.radius;
+    for(int i = 0; i < 3; ++i) a.offset[i] = p.offset[i];
+    a.hh_ratio = p.hh_ratio;
+    a.thresholds = b->d_thr;
+    a.flags = b->d_flags; a.zeros = b->d_zeros; a.attribute = b->d_attr; a.seeds = b->d_seeds; a.seed_count = b->d_seed_count;
+    return a;
+}
+
+// LongReadProbe::searchSeedsWithHybridKmers for every read of the resident batch: grid -> scan-k-mer
+// classes -> prefix sums -> per-position attribute -> per-read greedy scan.
+extern "C" int lrsc_batch_find_seeds(lrsc_ctx* ctx, lrsc_batch* b)
+{
+    if(!ctx || !b || b->ctx != ctx) return fail(LRSC_ERR_ARG, "batch does not belong to this ctx");
+    if(ctx->params.kmer_len_up_bound > 50) return fail(LRSC_ERR_ARG, "kmer_len_up_bound must be <= 50 (threshold table)");
+    if(ctx->params.manual && (ctx->params.mode < 0 || ctx->params.mode > 2)) return fail(LRSC_ERR_ARG, "mode must be 0, 1 or 2");
+    int st = lrsc_batch_kmer_grid(ctx, b);
+    if(st != LRSC_OK) return st;
+    st = batch_setup_seeds(ctx, b);
+    if(st != LRSC_OK) return st;
+    const SeedArgs a = batch_seed_args(ctx, b);
+    st = timed_launch(ctx, LRSC_K_SEEDS, [&]() {
+        hipError_t e = launch_seed_modes(a, ctx->stream);
+        if(e == hipSuccess) e = scan_seed_flags(b->d_flags, b->d_zeros, b->total_bases, &b->d_scan_tmp, &b->scan_tmp_cap, ctx->stream);
+        if(e == hipSuccess) e = launch_seed_attribute(a, ctx->stream);
+        if(e == hipSuccess) e = launch_seed_scan(ctx->fm, a, b->min_k, ctx->d_ctr, ctx->stream);
+        return e;
+    });
+    if(st == LRSC_OK) b->seeds_done = true;
+    return st;
+}
+
+extern "C" int lrsc_batch_seeds(lrsc_ctx* ctx, lrsc_batch* b, uint32_t* seed_count, lrsc_seed* seeds, uint64_t cap,
+                                uint64_t* n_seeds, int8_t* attribute)
+{
+    if(!ctx || !b || b->ctx != ctx || !seed_count || !n_seeds) return fail(LRSC_ERR_ARG, "null / foreign batch");
+    if(!b->seeds_done) return fail(LRSC_ERR_ARG, "call lrsc_batch_find_seeds first");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpy(seed_count, b->d_seed_count, (size_t)b->n_reads * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    std::vector<uint64_t> off(b->n_reads + 1);
+    HIP_TRY(hipMemcpy(off.data(), b->d_off, off.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    uint64_t total = 0;
+    for(uint32_t r = 0; r < b->n_reads; ++r) total += seed_count[r];
+    *n_seeds = total;
+    if(total > cap) return fail(LRSC_ERR_CAPACITY, "seed buffer too small");
+    if(seeds) {
+        static_assert(sizeof(lrsc_seed) == kSeedInts * sizeof(int32_t), "lrsc_seed layout");
+        uint64_t w = 0;
+        for(uint32_t r = 0; r < b->n_reads; ++r) {
+            if(seed_count[r] == 0) continue;
+            const uint64_t slab = seed_slab(off[r], r, b->min_k);
+            HIP_TRY(hipMemcpy(seeds + w, b->d_seeds + slab * kSeedInts, (size_t)seed_count[r] * sizeof(lrsc_seed),
+                              hipMemcpyDeviceToHost));
+            w += seed_count[r];
+        }
+    }
+    if(attribute) HIP_TRY(hipMemcpy(attribute, b->d_attr, b->total_bases, hipMemcpyDeviceToHost));
+    return LRSC_OK;
+}
+
+extern "C" int lrsc_find_seeds(lrsc_ctx* ctx, const char* reads, const uint64_t* read_off, uint32_t n_reads,
+                               uint32_t* seed_count, lrsc_seed* seeds, uint64_t cap, uint64_t* n_seeds, int8_t* attribute)
+{
+    lrsc_batch* b = nullptr;
+    int st = lrsc_batch_create(ctx, reads, read_off, n_reads, &b);
+    if(st != LRSC_OK) return st;
+    st = lrsc_batch_find_seeds(ctx, b);
+    if(st == LRSC_OK) st = lrsc_batch_seeds(ctx, b, seed_count, seeds, cap, n_seeds, attribute);
+    lrsc_batch_destroy(b);
+    return st;
 }

@@ -30,10 +30,47 @@ struct GridArgs {
     uint8_t* out_size;            // [pos * n_k + slot]
     uint8_t* out_count;           // [(pos * n_k + slot) * 4]
     // compact outputs (any may be null): structure-of-arrays, slot-major
-    int32_t* freq;                // [slot * total_bases + pos]  KmerFeature::getFreq() (-1 == fake)
+    int32_t* freq;                // [freq_index[slot] * total_bases + pos]  KmerFeature::getFreq() (-1 == fake)
+    int8_t freq_index[kMaxPool];  // compact row of `freq` for a slot, -1 = not stored
+    uint8_t* valid_mask;          // [pos] bit freq_index[slot] = both strands' intervals valid (KmerFeature::isValid)
     uint8_t* base_counted;        // [pos] chars counted by the base-slot search (<= ks[0])
     lrsc_biinterval* slot_iv;     // [slot * total_bases + pos] (only if non-null)
 };
+
+// LongReadProbe on the device (seeds.hip)
+constexpr uint32_t kSeedInts = 8;   // seedStartPos, seedLen, maxFixedMerFreq, isRepeat, startBestK, endBestK, startKmerFreq, endKmerFreq
+struct SeedArgs {
+    const uint8_t* codes;
+    const uint64_t* read_off;
+    const uint32_t* chunk_read;
+    uint64_t total_bases;
+    uint32_t n_reads;
+    // grid features (see GridArgs)
+    const int32_t* freq;
+    const uint8_t* valid_mask;
+    const uint8_t* base_counted;
+    int8_t row_of_k[64];          // freq row of a k-mer size, -1 if that size is not in the pool
+    uint32_t base_k;
+    // ProbeParameters (PacBio/LongReadProbe.h:7-40)
+    int32_t start_kmer_len, scan_kmer_len, kmer_len_up_bound, pb_coverage, mode, manual, radius;
+    int32_t offset[3];
+    float hh_ratio;
+    const float* thresholds;      // KmerThreshold table, [3][52]
+    // scratch / outputs
+    unsigned long long* flags;    // [pos] (repeat) | (garbage << 32), later its inclusive scan
+    uint32_t* zeros;              // [pos] zero-frequency non-low-complexity scan k-mers, later its inclusive scan
+    uint8_t* attribute;           // [pos] 1 unique / 2 repeat (LongReadProbe::getSeqAttribute)
+    int32_t* seeds;               // kSeedInts per seed, read r's slab starts at seed_slab(r)
+    uint32_t* seed_count;         // [read]
+};
+// first seed record of read r: reads can hold at most len/15 + 1 seeds (static k-mers are >= 15 long... any k >= 1: len + 1)
+__host__ __device__ inline uint64_t seed_slab(uint64_t read_start, uint32_t r, uint32_t min_k) { return read_start / min_k + r; }
+
+hipError_t launch_seed_modes(const SeedArgs& a, hipStream_t stream);
+hipError_t launch_seed_attribute(const SeedArgs& a, hipStream_t stream);
+hipError_t launch_seed_scan(const FmIndexDev& fm, const SeedArgs& a, uint32_t min_k, DevCounters* ctr, hipStream_t stream);
+// inclusive scans of SeedArgs::flags / zeros in place (hipCUB); tmp is grown as needed
+hipError_t scan_seed_flags(unsigned long long* flags, uint32_t* zeros, uint64_t n, void** tmp, size_t* tmp_cap, hipStream_t stream);
 
 hipError_t launch_rank(const FmIndexDev& fm, const lrsc_rank_query* q, uint64_t n, uint64_t* out,
                        DevCounters* ctr, hipStream_t stream);

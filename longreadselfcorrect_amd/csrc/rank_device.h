@@ -1,0 +1,300 @@
+// rank_device.h -- device-side FM-index primitives shared by every kernel file: block layouts,
+// in-block rank (bit planes + LDS mask table), updateInterval / initInterval, the k-mer walk.
+// Included only from .hip translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace lrsc {
+
+// ---------------------------------------------------------------------------------------
+// layouts
+// ---------------------------------------------------------------------------------------
+template <bool WIDE> struct Lay;
+
+template <> struct Lay<false> {
+    using pos_t = uint32_t;
+    static constexpr uint32_t kSyms = Block32::kSyms;
+    static constexpr uint32_t kWords = Block32::kWords;
+    static constexpr uint32_t kRow = 8;                    // mask-table row stride (u32)
+    struct Regs { uint4 q[4]; };                           // q0 = counts, q1..q3 = lo[6], hi[6]
+    static __device__ __forceinline__ void load(const void* blocks, uint64_t b, Regs& r)
+    {
+        const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const Block32*>(blocks) + b);
+        r.q[0] = p[0]; r.q[1] = p[1]; r.q[2] = p[2]; r.q[3] = p[3];
+    }
+    static __device__ __forceinline__ bool flagged(const Regs& r) { return (r.q[0].x & kFlag32) != 0; }
+    // symbols equal to `code` among the first `off` symbols of the block + the block's base count
+    static __device__ __forceinline__ uint64_t count(const Regs& r, uint32_t code, const uint32_t* __restrict__ mrow)
+    {
+        const uint32_t base = code == 0 ? (r.q[0].x & ~kFlag32) : code == 1 ? r.q[0].y : code == 2 ? r.q[0].z : r.q[0].w;
+        const uint32_t L = (code & 1u) ? 0u : 0xFFFFFFFFu;
+        const uint32_t H = (code & 2u) ? 0u : 0xFFFFFFFFu;
+        const uint4 m0 = *reinterpret_cast<const uint4*>(mrow);
+        const uint2 m1 = *reinterpret_cast<const uint2*>(mrow + 4);
+        uint32_t c = base;
+        c += __builtin_popcount((r.q[1].x ^ L) & (r.q[2].z ^ H) & m0.x);
+        c += __builtin_popcount((r.q[1].y ^ L) & (r.q[2].w ^ H) & m0.y);
+        c += __builtin_popcount((r.q[1].z ^ L) & (r.q[3].x ^ H) & m0.z);
+        c += __builtin_popcount((r.q[1].w ^ L) & (r.q[3].y ^ H) & m0.w);
+        c += __builtin_popcount((r.q[2].x ^ L) & (r.q[3].z ^ H) & m1.x);
+        c += __builtin_popcount((r.q[2].y ^ L) & (r.q[3].w ^ H) & m1.y);
+        return c;
+    }
+    static __device__ __forceinline__ uint32_t symbol(const Regs& r, uint32_t off)
+    {
+        const uint32_t lo[6] = {r.q[1].x, r.q[1].y, r.q[1].z, r.q[1].w, r.q[2].x, r.q[2].y};
+        const uint32_t hi[6] = {r.q[2].z, r.q[2].w, r.q[3].x, r.q[3].y, r.q[3].z, r.q[3].w};
+        uint32_t l = 0, h = 0;
+#pragma unroll
+        for(uint32_t i = 0; i < 6; ++i) { l = (off >> 5) == i ? lo[i] : l; h = (off >> 5) == i ? hi[i] : h; }
+        return ((l >> (off & 31u)) & 1u) | (((h >> (off & 31u)) & 1u) << 1);
+    }
+};
+
+template <> struct Lay<true> {
+    using pos_t = uint64_t;
+    static constexpr uint32_t kSyms = Block64::kSyms;
+    static constexpr uint32_t kWords = Block64::kWords;
+    static constexpr uint32_t kRow = 4;
+    struct Regs { uint4 q[4]; };                           // q0,q1 = counts, q2 = lo[4], q3 = hi[4]
+    static __device__ __forceinline__ void load(const void* blocks, uint64_t b, Regs& r)
+    {
+        const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const Block64*>(blocks) + b);
+        r.q[0] = p[0]; r.q[1] = p[1]; r.q[2] = p[2]; r.q[3] = p[3];
+    }
+    static __device__ __forceinline__ uint64_t u64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
+    static __device__ __forceinline__ bool flagged(const Regs& r) { return (r.q[0].y & 0x80000000u) != 0; }
+    static __device__ __forceinline__ uint64_t count(const Regs& r, uint32_t code, const uint32_t* __restrict__ mrow)
+    {
+        const uint64_t base = code == 0 ? (u64(r.q[0].x, r.q[0].y) & ~kFlag64) : code == 1 ? u64(r.q[0].z, r.q[0].w)
+                            : code == 2 ? u64(r.q[1].x, r.q[1].y) : u64(r.q[1].z, r.q[1].w);
+        const uint32_t L = (code & 1u) ? 0u : 0xFFFFFFFFu;
+        const uint32_t H = (code & 2u) ? 0u : 0xFFFFFFFFu;
+        const uint4 m0 = *reinterpret_cast<const uint4*>(mrow);
+        uint32_t c = 0;
+        c += __builtin_popcount((r.q[2].x ^ L) & (r.q[3].x ^ H) & m0.x);
+        c += __builtin_popcount((r.q[2].y ^ L) & (r.q[3].y ^ H) & m0.y);
+        c += __builtin_popcount((r.q[2].z ^ L) & (r.q[3].z ^ H) & m0.z);
+        c += __builtin_popcount((r.q[2].w ^ L) & (r.q[3].w ^ H) & m0.w);
+        return base + c;
+    }
+    static __device__ __forceinline__ uint32_t symbol(const Regs& r, uint32_t off)
+    {
+        const uint32_t lo[4] = {r.q[2].x, r.q[2].y, r.q[2].z, r.q[2].w};
+        const uint32_t hi[4] = {r.q[3].x, r.q[3].y, r.q[3].z, r.q[3].w};
+        uint32_t l = 0, h = 0;
+#pragma unroll
+        for(uint32_t i = 0; i < 4; ++i) { l = (off >> 5) == i ? lo[i] : l; h = (off >> 5) == i ? hi[i] : h; }
+        return ((l >> (off & 31u)) & 1u) | (((h >> (off & 31u)) & 1u) << 1);
+    }
+};
+
+// LDS table: row `off` holds the kWords partial-word masks for "the first off symbols of a block"
+template <bool WIDE>
+__device__ __forceinline__ void init_mask_table(uint32_t* tab)
+{
+    using L = Lay<WIDE>;
+    for(uint32_t i = threadIdx.x; i < (L::kSyms + 1) * L::kRow; i += blockDim.x) {
+        const uint32_t off = i / L::kRow, w = i % L::kRow;
+        tab[i] = w < L::kWords ? low_mask((int32_t)off - 32 * (int32_t)w) : 0u;
+    }
+    __syncthreads();
+}
+template <bool WIDE> struct MaskTabSize { static constexpr uint32_t value = (Lay<WIDE>::kSyms + 1) * Lay<WIDE>::kRow; };
+
+// Per-strand constants as plain scalars (wave-uniform, live in SGPRs).  Built from the kernel
+// argument with constant member indices only: indexing the by-value argument struct dynamically
+// makes the compiler copy it to scratch.
+template <class P>
+struct StrandC {
+    const void* blocks;
+    const uint64_t* dollars;
+    uint64_t n_dollars;
+    P c1, c2, c3, c4, n;      // C[A], C[C], C[G], C[T], N
+};
+template <class P>
+__device__ __forceinline__ StrandC<P> strand_consts(const FmStrand& s)
+{
+    StrandC<P> c;
+    c.blocks = s.blocks; c.dollars = s.dollars; c.n_dollars = s.n_dollars;
+    c.c1 = (P)s.pred[1]; c.c2 = (P)s.pred[2]; c.c3 = (P)s.pred[3]; c.c4 = (P)s.pred[4]; c.n = (P)s.n_symbols;
+    return c;
+}
+// C[code + 1] without a table: three predicated adds of uniform deltas
+template <class P>
+__device__ __forceinline__ P pred_of(const StrandC<P>& s, uint32_t code)
+{
+    P v = s.c1;
+    v += code >= 1 ? (s.c2 - s.c1) : 0;
+    v += code >= 2 ? (s.c3 - s.c2) : 0;
+    v += code >= 3 ? (s.c4 - s.c3) : 0;
+    return v;
+}
+// C[code + 2] (or N for T): upper end of the single-symbol interval
+template <class P>
+__device__ __forceinline__ P pred_next(const StrandC<P>& s, uint32_t code)
+{
+    P v = s.c2;
+    v += code >= 1 ? (s.c3 - s.c2) : 0;
+    v += code >= 2 ? (s.c4 - s.c3) : 0;
+    v += code >= 3 ? (s.n - s.c4) : 0;
+    return v;
+}
+template <class P>
+__device__ __forceinline__ uint64_t dollars_in_c(const StrandC<P>& s, uint64_t lo, uint64_t hi)
+{
+    uint64_t a = 0, b = s.n_dollars;
+    while(a < b) { const uint64_t m = (a + b) >> 1; if(s.dollars[m] < lo) a = m + 1; else b = m; }
+    const uint64_t first = a;
+    b = s.n_dollars;
+    while(a < b) { const uint64_t m = (a + b) >> 1; if(s.dollars[m] < hi) a = m + 1; else b = m; }
+    return a - first;
+}
+
+// Occ over the first p symbols (p = idx + 1, 0 <= p <= N): RLBWT::getOcc (RLBWT.h:121-140)
+template <bool WIDE>
+__device__ __forceinline__ uint64_t occ_prefix(const StrandC<typename Lay<WIDE>::pos_t>& s, uint32_t code,
+                                               typename Lay<WIDE>::pos_t p, const uint32_t* __restrict__ mtab)
+{
+    using L = Lay<WIDE>;
+    const typename L::pos_t b = p / L::kSyms;
+    const uint32_t off = (uint32_t)(p - b * L::kSyms);
+    typename L::Regs r;
+    L::load(s.blocks, b, r);
+    uint64_t c = L::count(r, code, mtab + off * L::kRow);
+    if(code == 0 && off != 0 && L::flagged(r)) c -= dollars_in_c(s, (uint64_t)b * L::kSyms, (uint64_t)b * L::kSyms + off);
+    return c;
+}
+
+template <class P> struct IvT { P lo, hi; };   // lower, upper; upper stored as-is (>= 0 always: pred >= 1)
+
+// BWTAlgorithms::updateInterval (BWTAlgorithms.h:66-72) on one strand.  The second block is only
+// loaded when the two rank positions straddle a block boundary.
+template <bool WIDE>
+__device__ __forceinline__ IvT<typename Lay<WIDE>::pos_t> update_interval(const StrandC<typename Lay<WIDE>::pos_t>& s, uint32_t code,
+                                                                          IvT<typename Lay<WIDE>::pos_t> iv,
+                                                                          const uint32_t* __restrict__ mtab, uint32_t& n_blk)
+{
+    using L = Lay<WIDE>;
+    using P = typename L::pos_t;
+    const P pl = iv.lo;            // (lower - 1) + 1
+    const P pu = iv.hi + 1;        // upper + 1
+    const P bl = pl / L::kSyms, bu = pu / L::kSyms;
+    const uint32_t ol = (uint32_t)(pl - bl * L::kSyms), ou = (uint32_t)(pu - bu * L::kSyms);
+    typename L::Regs ra, rb;
+    L::load(s.blocks, bl, ra);
+    rb = ra;
+    if(bu != bl) L::load(s.blocks, bu, rb);
+    uint64_t ca = L::count(ra, code, mtab + ol * L::kRow);
+    uint64_t cb = L::count(rb, code, mtab + ou * L::kRow);
+    if(code == 0) {
+        if(ol != 0 && L::flagged(ra)) ca -= dollars_in_c(s, (uint64_t)bl * L::kSyms, (uint64_t)bl * L::kSyms + ol);
+        if(ou != 0 && L::flagged(rb)) cb -= dollars_in_c(s, (uint64_t)bu * L::kSyms, (uint64_t)bu * L::kSyms + ou);
+    }
+    const P pb = pred_of(s, code);
+    IvT<P> out;
+    out.lo = pb + (P)ca;
+    out.hi = pb + (P)cb - 1;
+    n_blk += (bl == bu) ? 1u : 2u;
+    return out;
+}
+
+// BWTAlgorithms::initInterval (BWTAlgorithms.h:136-140): Occ(b, N-1) is the symbol total.
+template <class P>
+__device__ __forceinline__ IvT<P> init_interval(const StrandC<P>& s, uint32_t code)
+{
+    IvT<P> iv;
+    iv.lo = pred_of(s, code);
+    iv.hi = pred_next(s, code) - 1;
+    return iv;
+}
+
+__device__ __forceinline__ void flush_counters(DevCounters* ctr, uint32_t n_rank, uint32_t n_blk)
+{
+    if(ctr == nullptr) return;
+    unsigned long long a = n_rank, b = n_blk;
+#pragma unroll
+    for(int o = 32; o > 0; o >>= 1) {
+        a += __shfl_down(a, o, 64);
+        b += __shfl_down(b, o, 64);
+    }
+    if((threadIdx.x & 63) == 0) {
+        atomicAdd(&ctr->rank_queries, a);
+        atomicAdd(&ctr->block_loads, b);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// The k-mer walk shared by lrsc_find_kmers and lrsc_kmer_grid.
+//
+// A lane owns one start position and steps left-to-right through the read: the fwd interval
+// is the backward search of reverse(w) in the rbwt, the rvc interval the backward search of
+// revcomp(w) in the bwt, so both consume w[0], w[1], ... in order (BWTAlgorithms.cpp:32-38).
+// Steps < base_k reproduce findInterval's early exit per strand (BWTAlgorithms.cpp:28): a strand
+// that went invalid keeps its interval until step base_k; steps >= base_k are
+// KmerFeature::expand (KmerFeature.h:92-99): always applied, no validity check.
+// ---------------------------------------------------------------------------------------
+template <class P>
+struct WalkState {
+    IvT<P> fwd, rvc;
+    uint32_t size;          // bases consumed
+    uint32_t counted;       // bases counted by the base search (fwd strand)
+    uint32_t n_rank, n_blk; // accounting: Occ queries issued / rank blocks needed
+    bool fwd_broken, rvc_broken;
+};
+template <class P>
+__device__ __forceinline__ WalkState<P> walk_init()
+{
+    WalkState<P> st;
+    st.size = 0; st.counted = 0; st.n_rank = 0; st.n_blk = 0; st.fwd_broken = false; st.rvc_broken = false;
+    st.fwd.lo = st.fwd.hi = st.rvc.lo = st.rvc.hi = 0;
+    return st;
+}
+
+template <bool WIDE>
+__device__ __forceinline__ WalkState<typename Lay<WIDE>::pos_t>
+walk_step(const StrandC<typename Lay<WIDE>::pos_t>& sf, const StrandC<typename Lay<WIDE>::pos_t>& sr, uint32_t c,
+          uint32_t base_k, WalkState<typename Lay<WIDE>::pos_t> st, const uint32_t* __restrict__ mtab)
+{
+    using P = typename Lay<WIDE>::pos_t;
+    if(st.size == 0) {
+        st.fwd = init_interval<P>(sf, c);
+        st.rvc = init_interval<P>(sr, 3u - c);
+        st.counted = 1;
+        st.n_rank += 2;   // initInterval's getOcc(b, N-1) per strand (served from C[] here)
+    } else {
+        const bool in_base = st.size < base_k;
+        const bool do_f = !(in_base && st.fwd_broken);
+        const bool do_r = !(in_base && st.rvc_broken);
+        uint32_t bf = 0, br = 0;
+        const IvT<P> nf = update_interval<WIDE>(sf, c, st.fwd, mtab, bf);
+        const IvT<P> nr = update_interval<WIDE>(sr, 3u - c, st.rvc, mtab, br);
+        if(do_f) {
+            st.fwd = nf;
+            st.counted += in_base ? 1u : 0u;
+            st.fwd_broken = in_base && (nf.lo > nf.hi);
+            st.n_rank += 2; st.n_blk += bf;
+        }
+        if(do_r) {
+            st.rvc = nr;
+            st.rvc_broken = in_base && (nr.lo > nr.hi);
+            st.n_rank += 2; st.n_blk += br;
+        }
+    }
+    ++st.size;
+    return st;
+}
+
+template <class P> __device__ __forceinline__ int64_t iv_freq(const IvT<P>& iv) { return iv.lo <= iv.hi ? (int64_t)(iv.hi - iv.lo) + 1 : 0; }
+template <class P> __device__ __forceinline__ lrsc_biinterval to_out(const IvT<P>& f, const IvT<P>& r)
+{
+    lrsc_biinterval o;
+    o.fwd.lower = (int64_t)f.lo; o.fwd.upper = (int64_t)f.hi;
+    o.rvc.lower = (int64_t)r.lo; o.rvc.upper = (int64_t)r.hi;
+    return o;
+}
+
+
+} // namespace lrsc

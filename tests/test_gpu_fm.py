@@ -145,3 +145,63 @@ def test_stats_count_block_loads(gpu_ctx, small_ds):
     assert st.launches == 1 and st.total_ms > 0
     assert 0.97 * 74 * total <= st.rank_queries <= 74 * total
     assert (st.rank_queries - 2 * total) // 2 <= st.block_loads <= st.rank_queries
+
+
+# ---- LongReadProbe seeds --------------------------------------------------------------------------
+def _seed_case(api, gpu_index, oracle, small_ds, params, bases, off):
+    ctx = gpu_index.ctx(params, 0)
+    b = ctx.batch(bases, off)
+    b.find_seeds()
+    count, seeds, attr = b.seeds()
+    b.close(); ctx.close()
+    ob, orb = oracle.bwt_load(small_ds.prefix + ".bwt"), oracle.bwt_load(small_ds.prefix + ".rbwt")
+    wcount, wseeds, wattr = oracle.find_seeds(ob, orb, params, bases, off)
+    ob.close(); orb.close()
+    np.testing.assert_array_equal(attr, wattr)
+    np.testing.assert_array_equal(count, wcount)
+    got = np.stack([seeds[f] for f in seeds.dtype.names], axis=1)
+    np.testing.assert_array_equal(got, wseeds)
+    return wcount, wseeds, wattr
+
+
+@pytest.fixture(scope="module")
+def gpu_index(api, small_ds):
+    idx = api.index_open(small_ds.prefix + ".bwt", small_ds.prefix + ".rbwt")
+    idx.upload(0)
+    yield idx
+    idx.close()
+
+
+@pytest.mark.parametrize("genome,cov", [(5, 90), (10, 90), (100, 90), (5, 60), (10, 30)])
+def test_seeds_match_oracle(api, gpu_index, oracle, small_ds, genome, cov):
+    """searchSeedsWithHybridKmers + estimateBestKmerSize + removeHitchhikingSeeds, every field bit-exact,
+    plus getSeqAttribute per base, over the whole small read set."""
+    p = api.params_default(genome, cov)
+    wcount, wseeds, _ = _seed_case(api, gpu_index, oracle, small_ds, p, small_ds.bases, small_ds.off)
+    if (genome, cov) == (5, 90):
+        assert wcount.sum() > 3 * small_ds.n_reads            # the regime the bench uses really finds seeds
+
+
+def test_seeds_edge_cases(api, gpu_index, oracle, small_ds):
+    """Reads shorter than k, reads absent from the index (zero-frequency scan k-mers drive box[-1] negative:
+    LongReadProbe.cpp:152-156 vs :163-168), homopolymers / low complexity, a repeat-rich chimera."""
+    from oracle.oracle_py import pack_reads
+
+    rng = np.random.default_rng(17)
+    real = small_ds.reads
+    foreign = "".join(rng.choice(list("ACGT"), size=900))
+    chimera = real[2][:400] + foreign[:300] + real[5][200:700] + "A" * 40 + real[7][:300]
+    reads = ["ACGT", real[0][:16], real[0][:17], real[0][:19], real[1][:60], foreign, chimera, "A" * 300, "AC" * 200,
+             real[3], real[4][100:101], real[6][:500] + real[6][:500]]
+    bases, off = pack_reads(reads)
+    for g in (5, 10):
+        p = api.params_default(g, 90)
+        _seed_case(api, gpu_index, oracle, small_ds, p, bases, off)
+
+
+def test_seeds_manual_mode(api, gpu_index, oracle, small_ds):
+    p = api.params_default(5, 90)
+    p.manual, p.mode = 1, 2
+    n = 30
+    off = small_ds.off[: n + 1].copy()
+    _seed_case(api, gpu_index, oracle, small_ds, p, small_ds.bases[: int(off[-1])], off)

@@ -1,0 +1,97 @@
+"""CPU-only checks of the product's host logic and of the C-ABI surface (no compute calls without a GPU)."""
+import ctypes as C
+import json
+import subprocess
+
+import numpy as np
+import pytest
+
+from .conftest import GOLDEN, REPO
+
+
+def test_library_exports_every_declared_symbol(api):
+    from longreadselfcorrect_amd.capi import declared_symbols
+
+    names = declared_symbols()
+    assert len(names) >= 25 and "lrsc_kmer_grid" in names and "lrsc_batch_find_seeds" in names
+    exported = subprocess.run(["nm", "-D", "--defined-only", str(api.path)], capture_output=True, text=True, check=True).stdout
+    for n in names:
+        assert f" T {n}\n" in exported, f"{n} declared in include/lrsc.h but not exported"
+
+
+def test_header_is_plain_c(tmp_path):
+    src = tmp_path / "t.c"
+    src.write_text('#include "lrsc.h"\nint main(void){ lrsc_params p; (void)p; return lrsc_abi_version() == LRSC_ABI_VERSION ? 0 : 1; }\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", f"-I{REPO / 'include'}", str(src)], check=True)
+
+
+def test_params_default_reproduces_driver_derivation(api):
+    # StriDe/PacBioSelfCorrection.cpp:195-200
+    p = api.params_default(5, 90)
+    assert (p.start_kmer_len, list(p.offset)) == (17, [0, 2, -2])
+    p = api.params_default(10, 90)
+    assert (p.start_kmer_len, list(p.offset)) == (19, [0, 4, -4])
+    p = api.params_default(100, 90)
+    assert (p.start_kmer_len, list(p.offset)) == (21, [0, 4, -6])
+    p = api.params_default(10, 30)
+    assert list(p.offset) == [0, 0, -4]
+    assert (p.scan_kmer_len, p.kmer_len_up_bound, p.radius, p.max_leaves, p.idmer_len, p.min_kmer_len) == (19, 50, 100, 32, 9, 13)
+    assert np.float32(p.hh_ratio) == np.float32(0.6)
+    from longreadselfcorrect_amd import LrscError
+    with pytest.raises(LrscError):
+        api.params_default(7, 90)
+
+
+def test_product_threshold_table_matches_reference_golden(api):
+    """The product computes KmerThreshold on the host with its own code; golden = reference object code."""
+    gold = json.loads((GOLDEN / "threshold_tables.json").read_text())
+    for cov, rows in gold.items():
+        assert api.kmer_thresholds(int(cov)).tobytes() == np.array(rows, dtype=np.float32).tobytes(), cov
+
+
+def test_bad_bwt_files_report_format_errors(api, tmp_path, small_ds):
+    from longreadselfcorrect_amd import LrscError
+
+    bad = tmp_path / "bad.bwt"
+    bad.write_bytes(b"\x00" * 64)
+    with pytest.raises(LrscError) as ei:
+        api.index_open(bad, small_ds.prefix + ".rbwt")
+    assert ei.value.status == -2 and "not properly formatted" in ei.value.detail      # BWTReaderBinary.cpp:61-65
+    with pytest.raises(LrscError) as ei:
+        api.index_open(tmp_path / "missing.bwt", small_ds.prefix + ".rbwt")
+    assert ei.value.status == -1
+    trunc = tmp_path / "trunc.bwt"
+    trunc.write_bytes(open(small_ds.prefix + ".bwt", "rb").read()[:1000])
+    with pytest.raises(LrscError) as ei:
+        api.index_open(trunc, small_ds.prefix + ".rbwt")
+    assert ei.value.status == -2
+
+
+def test_host_image_build_and_no_device(api, small_ds):
+    """Index parsing + rank-block image is host work; compute needs a device and says so."""
+    from longreadselfcorrect_amd import LrscError
+
+    idx = api.index_open(small_ds.prefix + ".bwt", small_ds.prefix + ".rbwt")
+    info = idx.info()
+    assert info.num_strings == small_ds.n_reads and info.num_symbols == int(small_ds.off[-1]) + small_ds.n_reads
+    assert info.block_bytes == 64 and info.block_symbols == 192
+    assert info.device_bytes >= 2 * (info.num_symbols // 192) * 64
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(LrscError) as ei:
+            idx.upload(0)
+        assert ei.value.status == -5          # LRSC_ERR_DEVICE: no CPU fallback
+    idx.close()
+
+
+def test_synthetic_reads_are_deterministic_and_shardable(api):
+    g = api.synth_genome(7, 20000)
+    assert set(np.unique(g)) == set(b"ACGT")
+    b1, o1 = api.synth_reads(9, g, 40, 1000)
+    b2, o2 = api.synth_reads(9, g, 40, 1000)
+    assert np.array_equal(b1, b2) and np.array_equal(o1, o2)
+    # shard [10, 25) generated on its own equals the slice of the whole
+    bs, os_ = api.synth_reads(9, g, 15, 1000, first_read=10)
+    assert np.array_equal(bs, b1[int(o1[10]): int(o1[25])])
+    lens = np.diff(o1.astype(np.int64))
+    assert 950 < lens.mean() < 1150                      # -4.5% del, +9% ins
