@@ -122,6 +122,8 @@ __device__ __forceinline__ int64_t find_run(const StrandC<typename Lay<WIDE>::po
     return iv_freq(iv);
 }
 
+constexpr uint32_t kReadsPerWave = 16;
+
 struct DynKmer {          // the part of KmerFeature the scan needs
     int size;
     int freq;             // frequency (valid when !fake)
@@ -134,9 +136,12 @@ __global__ __launch_bounds__(64) void seed_scan_kernel(FmIndexDev fm, SeedArgs a
     using P = typename Lay<WIDE>::pos_t;
     __shared__ __attribute__((aligned(16))) uint32_t mtab[MaskTabSize<WIDE>::value];
     init_mask_table<WIDE>(mtab);
-    const uint32_t r = blockIdx.x * 64 + threadIdx.x;
+    // kReadsPerWave of the 64 lanes own a read: the scan is a divergent sequential state machine, and
+    // the FM work of different lanes of one wavefront serialises; fewer reads per wave, more waves.
+    const uint32_t r = blockIdx.x * kReadsPerWave + threadIdx.x / (64 / kReadsPerWave);
+    const bool owner = (threadIdx.x % (64 / kReadsPerWave)) == 0;
     uint32_t n_rank = 0, n_blk = 0;
-    if(r < a.n_reads) {
+    if(owner && r < a.n_reads) {
         const StrandC<P> sF = strand_consts<P>(fm.strand[LRSC_RBWT]);
         const StrandC<P> sR = strand_consts<P>(fm.strand[LRSC_BWT]);
         const uint64_t s = a.read_off[r], e = a.read_off[r + 1];
@@ -314,7 +319,7 @@ hipError_t launch_seed_attribute(const SeedArgs& a, hipStream_t stream)
 hipError_t launch_seed_scan(const FmIndexDev& fm, const SeedArgs& a, uint32_t min_k, DevCounters* ctr, hipStream_t stream)
 {
     if(a.n_reads == 0) return hipSuccess;
-    const unsigned nb = (a.n_reads + 63) / 64;
+    const unsigned nb = (a.n_reads + kReadsPerWave - 1) / kReadsPerWave;
     if(fm.wide) hipLaunchKernelGGL(seed_scan_kernel<true>, dim3(nb), dim3(64), 0, stream, fm, a, min_k, ctr);
     else        hipLaunchKernelGGL(seed_scan_kernel<false>, dim3(nb), dim3(64), 0, stream, fm, a, min_k, ctr);
     return hipGetLastError();
