@@ -193,6 +193,37 @@ int lrsc_batch_seeds(lrsc_ctx* ctx, lrsc_batch* b, uint32_t* seed_count, lrsc_se
 int lrsc_find_seeds(lrsc_ctx* ctx, const char* reads, const uint64_t* read_off, uint32_t n_reads,
                     uint32_t* seed_count, lrsc_seed* seeds, uint64_t cap, uint64_t* n_seeds, int8_t* attribute);
 
+/* ---- seed-to-seed FM-extend ----------------------------------------------------------------------- */
+/* One LongReadSelfCorrectByOverlap(sourceSeed, strBetweenSrcTarget, targetSeed, disBetweenSrcTarget,
+ * initkmersize, maxOverlap, FM_params, min_SA_threshold).extendOverlap(result) call
+ * (PacBio/LongReadCorrectByOverlap.cpp:17-95,155-211; built at PacBioSelfCorrectionProcess.cpp:186-190).
+ * The three strings are ASCII ACGT, concatenated at seq + seq_off. */
+typedef struct lrsc_walk_desc {
+    uint64_t seq_off;
+    uint32_t src_len;            /* sourceSeed length (>= init_kmer; its last init_kmer bases start the walk) */
+    uint32_t path_len;           /* strBetweenSrcTarget length                                                */
+    uint32_t trg_len;            /* targetSeed length                                                         */
+    int32_t  dis;                /* disBetweenSrcTarget                                                       */
+    uint32_t init_kmer;          /* initkmersize                                                              */
+    uint32_t max_overlap;        /* maxOverlap                                                                */
+    uint32_t min_sa_threshold;   /* min_SA_threshold                                                          */
+    uint32_t pad;
+} lrsc_walk_desc;
+typedef struct lrsc_walk_result {
+    int32_t  code;               /* extendOverlap's return value: 1, or -1 high error, -2 depth, -3 leaves, -4 */
+    uint32_t steps;              /* iterations of the extension loop (accounting)                              */
+    uint64_t out_off;            /* FMWalkResult2::mergedSeq at out_arena + out_off (code > 0 only)            */
+    uint32_t out_len;
+    uint32_t pad;
+} lrsc_walk_result;
+/* Runs n independent walks on the device.  out_arena receives the merged sequences back to back
+ * (*arena_used bytes); LRSC_ERR_CAPACITY if arena_cap is too small (then *arena_used = bytes needed). */
+int lrsc_extend_walks(lrsc_ctx* ctx, const char* seq, uint64_t seq_len, const lrsc_walk_desc* walks, uint32_t n,
+                      lrsc_walk_result* results, char* out_arena, uint64_t arena_cap, uint64_t* arena_used);
+/* Test hook: the permutation std::sort (libstdc++ introsort, comparator a.start > b.start) leaves n
+ * (key, index) pairs in -- the product's own re-implementation, run on the host. perm_out[j] = index. */
+int lrsc_debug_sort_order(const uint64_t* keys, uint32_t n, uint32_t* perm_out);
+
 /* ---- measurement ------------------------------------------------------------------------- */
 typedef struct lrsc_kernel_stats {
     uint64_t launches;          /* launches since the last reset                        */

@@ -72,6 +72,16 @@ class Params(C.Structure):
     ]
 
 
+class WalkDesc(C.Structure):
+    _fields_ = [("seq_off", C.c_uint64), ("src_len", C.c_uint32), ("path_len", C.c_uint32), ("trg_len", C.c_uint32),
+                ("dis", C.c_int32), ("init_kmer", C.c_uint32), ("max_overlap", C.c_uint32), ("min_sa_threshold", C.c_uint32),
+                ("pad", C.c_uint32)]
+
+
+class WalkResult(C.Structure):
+    _fields_ = [("code", C.c_int32), ("steps", C.c_uint32), ("out_off", C.c_uint64), ("out_len", C.c_uint32), ("pad", C.c_uint32)]
+
+
 class KernelStats(C.Structure):
     _fields_ = [
         ("launches", C.c_uint64),
@@ -151,6 +161,9 @@ class Lrsc:
                                        C.c_void_p]
         L.lrsc_find_seeds.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64,
                                       C.POINTER(C.c_uint64), C.c_void_p]
+        L.lrsc_extend_walks.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                        C.c_uint64, C.POINTER(C.c_uint64)]
+        L.lrsc_debug_sort_order.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         L.lrsc_ctx_stats.argtypes = [C.c_void_p, C.c_int, C.POINTER(KernelStats)]
         L.lrsc_ctx_stats_reset.argtypes = [C.c_void_p]
         L.lrsc_synth_genome.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p]
@@ -166,6 +179,12 @@ class Lrsc:
         p = Params()
         self.check(self.lib.lrsc_params_default(genome, coverage, C.byref(p)), "lrsc_params_default")
         return p
+
+    def debug_sort_order(self, keys: np.ndarray) -> np.ndarray:
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        perm = np.zeros(keys.size, dtype=np.uint32)
+        self.check(self.lib.lrsc_debug_sort_order(_ptr(keys), keys.size, _ptr(perm)), "lrsc_debug_sort_order")
+        return perm
 
     def kmer_thresholds(self, coverage: int) -> np.ndarray:
         out = np.zeros((3, 52), dtype=np.float32)
@@ -302,6 +321,32 @@ class Ctx:
         return (iv.reshape(shape) if iv is not None else None,
                 size.reshape(shape) if size is not None else None,
                 cnt.reshape(shape + (4,)) if cnt is not None else None)
+
+    def extend_walks(self, walks):
+        """walks: list of (src, path, trg, dis, init_kmer, max_overlap, min_sa).  -> list of (code, mergedSeq, steps)."""
+        n = len(walks)
+        descs = (WalkDesc * n)()
+        parts, off = [], 0
+        for i, (src, path, trg, dis, initk, maxov, minsa) in enumerate(walks):
+            d = descs[i]
+            d.seq_off, d.src_len, d.path_len, d.trg_len = off, len(src), len(path), len(trg)
+            d.dis, d.init_kmer, d.max_overlap, d.min_sa_threshold = dis, initk, maxov, minsa
+            parts += [src, path, trg]
+            off += len(src) + len(path) + len(trg)
+        seq = "".join(parts).encode()
+        res = (WalkResult * n)()
+        cap = max(1 << 16, 2 * len(seq) + 4096)
+        used = C.c_uint64()
+        while True:
+            arena = C.create_string_buffer(cap)
+            st = self.api.lib.lrsc_extend_walks(self.h, seq, len(seq), descs, n, res, arena, cap, C.byref(used))
+            if st == -6 and used.value > cap:
+                cap = int(used.value)
+                continue
+            self.api.check(st, "lrsc_extend_walks")
+            break
+        raw = arena.raw
+        return [(r.code, raw[r.out_off: r.out_off + r.out_len].decode() if r.code > 0 else "", r.steps) for r in res]
 
     def batch(self, bases: np.ndarray, off: np.ndarray) -> "Batch":
         bases = np.ascontiguousarray(bases, dtype=np.uint8)

@@ -21,6 +21,8 @@
 #include "../../include/lrsc.h"
 #include "fm_layout.h"
 #include "kernels.h"
+#include "extend.h"
+#include "introsort_emul.h"
 
 using namespace lrsc;
 
@@ -824,4 +826,172 @@ extern "C" int lrsc_find_seeds(lrsc_ctx* ctx, const char* reads, const uint64_t*
     if(st == LRSC_OK) st = lrsc_batch_seeds(ctx, b, seed_count, seeds, cap, n_seeds, attribute);
     lrsc_batch_destroy(b);
     return st;
+}
+
+// ---------------------------------------------------------------------------------------
+// FM-extend
+// ---------------------------------------------------------------------------------------
+extern "C" int lrsc_debug_sort_order(const uint64_t* keys, uint32_t n, uint32_t* perm_out)
+{
+    if((!keys || !perm_out) && n) return fail(LRSC_ERR_ARG, "null");
+    std::vector<SortItem> v(n);
+    for(uint32_t i = 0; i < n; ++i) { v[i].key = keys[i]; v[i].val = i; v[i].pad = 0; }
+    introsort(v.data(), (int64_t)n);
+    for(uint32_t i = 0; i < n; ++i) perm_out[i] = v[i].val;
+    return LRSC_OK;
+}
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+extern "C" int lrsc_extend_walks(lrsc_ctx* ctx, const char* seq, uint64_t seq_len, const lrsc_walk_desc* walks, uint32_t n,
+                                 lrsc_walk_result* results, char* out_arena, uint64_t arena_cap, uint64_t* arena_used)
+{
+    if(!ctx || (!walks && n) || (!results && n) || !arena_used) return fail(LRSC_ERR_ARG, "null");
+    *arena_used = 0;
+    if(n == 0) return LRSC_OK;
+    const lrsc_params& p = ctx->params;
+    if(p.max_leaves < 1 || p.max_leaves > 32) return fail(LRSC_ERR_UNSUPPORTED, "max_leaves must be 1..32");
+    if(p.idmer_len < 5 || p.idmer_len > 16) return fail(LRSC_ERR_UNSUPPORTED, "idmer_len must be 5..16");
+    if(p.min_kmer_len < p.idmer_len || p.min_kmer_len > 62) return fail(LRSC_ERR_UNSUPPORTED, "min_kmer_len out of range");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const bool wide = ctx->fm.wide != 0;
+    const size_t psz = wide ? 8 : 4;
+    const size_t lbytes = leaf_bytes(wide);
+
+    // ---- geometry, codes, workspace plan --------------------------------------------------------------
+    std::vector<WalkWork> work(n);
+    std::vector<uint64_t> q_off(n + 1, 0);
+    uint64_t codes_total = 0, ws_total = 0, out_total = 0;
+    for(uint32_t w = 0; w < n; ++w) {
+        const lrsc_walk_desc& d = walks[w];
+        if(d.init_kmer == 0 || d.src_len < d.init_kmer || d.init_kmer < (uint32_t)p.idmer_len || d.max_overlap + 1 > 62 ||
+           d.init_kmer > 62)
+            return fail(LRSC_ERR_ARG, "walk: init_kmer must satisfy idmer_len <= init_kmer <= src_len and max_overlap < 62");
+        if(d.trg_len < (uint32_t)p.min_kmer_len) return fail(LRSC_ERR_ARG, "walk: target seed shorter than min_kmer_len");
+        if(d.seq_off + (uint64_t)d.src_len + d.path_len + d.trg_len > seq_len) return fail(LRSC_ERR_ARG, "walk: sequence out of range");
+        WalkWork& ww = work[w];
+        ww.initk = d.init_kmer; ww.path_len = d.path_len; ww.trg_len = d.trg_len; ww.dis = d.dis;
+        ww.max_overlap = d.max_overlap; ww.min_sa = d.min_sa_threshold;
+        ww.lq = d.init_kmer + d.path_len + d.trg_len;
+        if(ww.lq >= 65535) return fail(LRSC_ERR_UNSUPPORTED, "walk: query longer than 65534 bases");
+        const double maxLength = (1.2 * (d.dis + 10)) + (double)(2 * (uint64_t)d.init_kmer);
+        if(maxLength < 0 || maxLength > 1e6) return fail(LRSC_ERR_ARG, "walk: dis out of range");
+        ww.pathw = (uint32_t)(((uint64_t)maxLength + 4 + 15) / 16 + 1);
+        ww.codes_off = codes_total;
+        codes_total += ww.lq;
+        q_off[w + 1] = q_off[w] + ww.lq;
+        const uint32_t n9 = ww.lq - (uint32_t)p.idmer_len + 1, n5 = ww.lq - 5 + 1;
+        const uint32_t nT = d.trg_len - (uint32_t)p.min_kmer_len + 1;
+        size_t o = 0;
+        ww.o_item9f = (uint32_t)o; o += (size_t)n9 * sizeof(SortItem);
+        ww.o_item9r = (uint32_t)o; o += (size_t)n9 * sizeof(SortItem);
+        ww.o_term = (uint32_t)o;   o = align_up(o + (size_t)nT * 4 * psz, 16);
+        ww.o_leaves = (uint32_t)o; o = align_up(o + (size_t)(32 + kMaxChildren) * lbytes, 16);
+        ww.o_rings = (uint32_t)o;  o += (size_t)32 * 100 * sizeof(double);
+        ww.o_results = (uint32_t)o; o += (size_t)kMaxResults * sizeof(WalkResultRec);
+        ww.o_paths = (uint32_t)o;  o += (size_t)(32 + kMaxResults) * ww.pathw * 4;
+        ww.o_next9f = (uint32_t)o; o += (size_t)n9 * 2;
+        ww.o_next9r = (uint32_t)o; o += (size_t)n9 * 2;
+        ww.o_head9 = (uint32_t)o;  o += 512 * 2;
+        ww.o_head5 = (uint32_t)o;  o += 1024 * 2;
+        ww.o_next5 = (uint32_t)o;  o += (size_t)n5 * 2;
+        ww.o_flags5 = (uint32_t)o; o += n5;
+        o = align_up(o, 64);
+        if(o >= (1ull << 32)) return fail(LRSC_ERR_UNSUPPORTED, "walk workspace too large");
+        ww.ws_off = ws_total;
+        ws_total += o;
+        ww.out_off = out_total;
+        out_total += (size_t)ww.pathw * 4;
+    }
+    std::vector<uint8_t> codes(codes_total);
+    for(uint32_t w = 0; w < n; ++w) {
+        const lrsc_walk_desc& d = walks[w];
+        const char* src = seq + d.seq_off + (d.src_len - d.init_kmer);     // beginningkmer = sourceSeed.substr(len - initk)
+        uint8_t* dst = codes.data() + work[w].codes_off;
+        for(uint32_t i = 0; i < work[w].lq; ++i) {
+            const char c = src[i];
+            uint8_t code;
+            switch(c) { case 'A': code = 0; break; case 'C': code = 1; break; case 'G': code = 2; break; case 'T': code = 3; break;
+                        default: return fail(LRSC_ERR_ARG, "sequence contains a base other than A,C,G,T"); }
+            dst[i] = code;
+        }
+    }
+    // launch order: long walks first, similar lengths share a wavefront
+    std::vector<uint32_t> order(n);
+    for(uint32_t i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return walks[a].dis > walks[b].dis; });
+
+    // pow() table of the constructor (.cpp:68-70), computed with the host libm like the reference does
+    double freqs[101];
+    for(int i = 0; i <= 100; ++i) freqs[i] = 0;
+    for(int i = p.min_kmer_len; i <= 100; i++) freqs[i] = pow(1 - p.error_rate, i) * (size_t)p.pb_coverage;
+
+    // ---- device buffers ------------------------------------------------------------------------------------
+    DevBuf<uint8_t> d_codes, d_ws, d_outp;
+    DevBuf<WalkWork> d_work;
+    DevBuf<uint64_t> d_qoff;
+    DevBuf<uint32_t> d_chunk, d_order;
+    DevBuf<WalkOut> d_out;
+    DevBuf<double> d_freqs;
+    const uint64_t total_q = q_off[n];
+    const uint64_t n_chunks = (total_q + (1ull << kChunkShift) - 1) >> kChunkShift;
+    HIP_TRY(d_codes.reserve(codes_total));
+    HIP_TRY(d_ws.reserve(ws_total));
+    HIP_TRY(d_outp.reserve(out_total));
+    HIP_TRY(d_work.reserve(n));
+    HIP_TRY(d_qoff.reserve(n + 1));
+    HIP_TRY(d_chunk.reserve(n_chunks));
+    HIP_TRY(d_order.reserve(n));
+    HIP_TRY(d_out.reserve(n));
+    HIP_TRY(d_freqs.reserve(101));
+    HIP_TRY(hipMemcpyAsync(d_codes.p, codes.data(), codes_total, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_work.p, work.data(), (size_t)n * sizeof(WalkWork), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_qoff.p, q_off.data(), (size_t)(n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_order.p, order.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_freqs.p, freqs, sizeof(freqs), hipMemcpyHostToDevice, ctx->stream));
+    hipError_t e = launch_chunk_table(d_qoff.p, n, total_q, d_chunk.p, ctx->stream);
+    if(e != hipSuccess) return hip_fail(e, "chunk_table");
+
+    ExtendArgs a{};
+    a.codes = d_codes.p; a.work = d_work.p; a.q_off = d_qoff.p; a.chunk_walk = d_chunk.p; a.order = d_order.p;
+    a.total_q = total_q; a.n_walks = n;
+    a.workspace = d_ws.p; a.out_paths = d_outp.p; a.out = d_out.p;
+    a.seed_size = (uint32_t)p.idmer_len; a.min_overlap = (uint32_t)p.min_kmer_len; a.max_leaves = (uint32_t)p.max_leaves;
+    a.pb_coverage = (uint64_t)p.pb_coverage; a.pacbio_error_rate = p.error_rate;
+    a.freqs_of_kmer_size = d_freqs.p;
+    a.ctr = ctx->d_ctr;
+    const int st = timed_launch(ctx, LRSC_K_EXTEND, [&]() {
+        hipError_t e2 = launch_walk_prepare(ctx->fm, a, ctx->stream);
+        if(e2 == hipSuccess) e2 = launch_walk_extend(ctx->fm, a, ctx->stream);
+        return e2;
+    });
+    if(st != LRSC_OK) return st;
+
+    std::vector<WalkOut> out(n);
+    std::vector<uint32_t> outp(out_total / 4);
+    HIP_TRY(hipMemcpy(out.data(), d_out.p, (size_t)n * sizeof(WalkOut), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(outp.data(), d_outp.p, out_total, hipMemcpyDeviceToHost));
+    uint64_t used = 0;
+    for(uint32_t w = 0; w < n; ++w) {
+        if(out[w].code <= LRSC_WALK_ERR_CHILDREN) return fail(LRSC_ERR_CAPACITY, "walk: internal frontier/result capacity exceeded");
+        results[w].code = out[w].code; results[w].steps = out[w].steps; results[w].out_off = used; results[w].out_len = 0; results[w].pad = 0;
+        if(out[w].code > 0) {
+            const lrsc_walk_desc& d = walks[w];
+            const uint32_t tail_from = out[w].match_i + (uint32_t)p.min_kmer_len;
+            const uint32_t tail = d.trg_len > (uint32_t)p.min_kmer_len && tail_from <= d.trg_len ? d.trg_len - tail_from : 0;
+            const uint32_t len = out[w].path_len + tail;
+            results[w].out_len = len;
+            if(out_arena && used + len <= arena_cap) {
+                char* dst = out_arena + used;
+                const uint32_t* pw = outp.data() + work[w].out_off / 4;
+                for(uint32_t i = 0; i < out[w].path_len; ++i) dst[i] = "ACGT"[(pw[i >> 4] >> (2 * (i & 15))) & 3u];
+                const char* trg = seq + d.seq_off + d.src_len + d.path_len;
+                for(uint32_t i = 0; i < tail; ++i) dst[out[w].path_len + i] = trg[tail_from + i];
+            }
+            used += len;
+        }
+    }
+    *arena_used = used;
+    if(used > arena_cap || (!out_arena && used)) return fail(LRSC_ERR_CAPACITY, "output arena too small");
+    return LRSC_OK;
 }

@@ -205,3 +205,65 @@ def test_seeds_manual_mode(api, gpu_index, oracle, small_ds):
     n = 30
     off = small_ds.off[: n + 1].copy()
     _seed_case(api, gpu_index, oracle, small_ds, p, small_ds.bases[: int(off[-1])], off)
+
+
+# ---- seed-to-seed FM-extend -------------------------------------------------------------------------
+_COMP = str.maketrans("ACGT", "TGCA")
+
+
+def _revcomp(s):
+    return s.translate(_COMP)[::-1]
+
+
+def _walk_descs(params, reads, count, seeds, max_per_read=1000):
+    """The descriptors correctByFMExtension builds (PacBioSelfCorrectionProcess.cpp:159-190) for consecutive seed
+    pairs, taking every source seed as found (no accumulated state) -- arbitrary but realistic walk inputs."""
+    descs = []
+    k = 0
+    for r, n in enumerate(count):
+        ss = seeds[k: k + n]
+        k += n
+        read = reads[r]
+        for i in range(min(max(int(n) - 1, 0), max_per_read)):
+            s, t = ss[i], ss[i + 1]
+            s_start, s_len, t_start, t_len = int(s[0]), int(s[1]), int(t[0]), int(t[1])
+            s_end = s_start + s_len - 1
+            interval = t_start - s_end - 1
+            ext = min(int(s[5]), int(t[4])) - 2                      # min(source.endBest, target.startBest) - 2
+            if s[3] or t[3]:
+                ext = min(min(s_len, t_len), params.start_kmer_len + 2)
+            src = read[s_start: s_start + s_len][s_len - ext:]
+            trg = read[t_start: t_start + t_len]
+            path = read[s_end + 1: s_end + 1 + interval]
+            min_sa = (params.pb_coverage // 60) * 3 if params.pb_coverage > 60 else 3
+            if s[3] and not t[3]:                                     # isFromRtoU: walk from the unique side
+                src, trg = _revcomp(trg), _revcomp(src)
+                path = _revcomp(path)
+            descs.append((src, path, trg, interval, ext, ext + 2, min_sa))
+    return descs
+
+
+@pytest.mark.parametrize("genome,cov", [(5, 90), (10, 90)])
+def test_extend_walks_match_oracle(api, gpu_index, oracle, small_ds, genome, cov):
+    """LongReadSelfCorrectByOverlap::extendOverlap: return code and merged sequence identical for every walk."""
+    p = api.params_default(genome, cov)
+    ob, orb = oracle.bwt_load(small_ds.prefix + ".bwt"), oracle.bwt_load(small_ds.prefix + ".rbwt")
+    n_reads = 40
+    off = small_ds.off[: n_reads + 1].copy()
+    bases = small_ds.bases[: int(off[-1])]
+    count, seeds, _ = oracle.find_seeds(ob, orb, p, bases, off)
+    descs = _walk_descs(p, small_ds.reads[:n_reads], count, seeds)
+    assert len(descs) > 100
+    ctx = gpu_index.ctx(p, 0)
+    got = ctx.extend_walks(descs)
+    ctx.close()
+    codes = {}
+    for d, (code, merged, steps) in zip(descs, got):
+        wcode, wmerged, wst = oracle.extend_walk(ob, orb, p, *d)
+        assert (code, merged) == (wcode, wmerged), d
+        assert steps == wst[0]
+        codes[wcode] = codes.get(wcode, 0) + 1
+    ob.close(); orb.close()
+    assert codes.get(1, 0) > len(descs) // 2          # most walks succeed ...
+    if (genome, cov) == (5, 90):
+        assert codes.get(-1, 0) > 0                    # ... and the failure path is exercised too

@@ -95,3 +95,37 @@ def test_synthetic_reads_are_deterministic_and_shardable(api):
     assert np.array_equal(bs, b1[int(o1[10]): int(o1[25])])
     lens = np.diff(o1.astype(np.int64))
     assert 950 < lens.mean() < 1150                      # -4.5% del, +9% ins
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 15, 16, 17, 33, 100, 281, 700, 3000])
+def test_introsort_emulation_matches_std_sort_order(api, ref, oracle, n):
+    """The product's re-implementation of libstdc++ std::sort must leave equal keys in the same order as the
+    reference's IntervalTree (reference object code) returns them."""
+    rng = np.random.default_rng(1000 + n)
+    shapes = ["few", "many", "equal", "asc", "desc", "pipe"]
+    for shape in shapes:
+        if n == 0:
+            assert api.debug_sort_order(np.zeros(0, dtype=np.uint64)).size == 0
+            return
+        if shape == "few":
+            keys = rng.integers(1, max(2, n // 9 + 2), size=n)
+        elif shape == "many":
+            keys = rng.integers(1, 10 * n + 2, size=n)
+        elif shape == "equal":
+            keys = np.full(n, 7)
+        elif shape == "asc":
+            keys = np.arange(n) // 3 + 1
+        elif shape == "desc":
+            keys = (n - np.arange(n)) // 2 + 1
+        else:
+            keys = np.minimum(np.arange(n), n - np.arange(n)) // 2 + 1
+        keys = keys.astype(np.uint64) * 1000
+        perm = api.debug_sort_order(keys)
+        assert sorted(perm.tolist()) == list(range(n))
+        assert np.all(np.diff(keys[perm].astype(np.int64)) <= 0)             # descending by key
+        uniq = np.unique(keys)
+        queries = [(int(k), int(k) + 5) for k in uniq]
+        want = ref.itree_query_all(keys, keys + 5, np.arange(n), queries)
+        for k, w in zip(uniq, want):
+            got = perm[keys[perm] == k]
+            np.testing.assert_array_equal(got, w, err_msg=f"n={n} shape={shape} key={k}")
