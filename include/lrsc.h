@@ -224,6 +224,26 @@ int lrsc_extend_walks(lrsc_ctx* ctx, const char* seq, uint64_t seq_len, const lr
  * (key, index) pairs in -- the product's own re-implementation, run on the host. perm_out[j] = index. */
 int lrsc_debug_sort_order(const uint64_t* keys, uint32_t n, uint32_t* perm_out);
 
+/* ---- the whole per-read path ------------------------------------------------------------------------ */
+/* PacBioSelfCorrectionResult (PacBio/PacBioSelfCorrectionProcess.h:58-94) without the wall-clock timers;
+ * correctedStrs = pieces [piece_first, piece_first + n_pieces). */
+typedef struct lrsc_read_result {
+    int32_t  merge;              /* !pieceVec.empty(): record goes to correct.fa, else the raw read to discard.fa */
+    uint32_t n_pieces;           /* 1, or more with --split                                                       */
+    uint64_t piece_first;
+    int64_t  total_reads_len, corrected_len, total_seed_num, total_walk_num, high_error_num, exceed_depth_num,
+             exceed_leave_num, fm_num, dp_num, seed_dis;
+} lrsc_read_result;
+/* PacBioSelfCorrectionProcess::process for every read of the batch (PacBioSelfCorrectionProcess.cpp:23-206):
+ * seeds and seed-to-seed FM-extension on the device, stitching on the host, with the ctx's parameters.
+ * Piece p is out[piece_off[p] .. piece_off[p+1]).  Needs params.no_dp (the DP/MSA fallback of
+ * correctByMSAlignment is not part of the product yet): LRSC_ERR_UNSUPPORTED otherwise.
+ * LRSC_ERR_CAPACITY (with *n_pieces / *out_used = what is needed) if piece_cap / out_cap are too small. */
+int lrsc_correct_reads(lrsc_ctx* ctx, const char* reads, const uint64_t* read_off, uint32_t n_reads,
+                       lrsc_read_result* results, uint64_t* piece_off, uint64_t piece_cap, char* out, uint64_t out_cap,
+                       uint64_t* n_pieces, uint64_t* out_used);
+int lrsc_ctx_get_params(const lrsc_ctx* ctx, lrsc_params* out);
+
 /* ---- measurement ------------------------------------------------------------------------- */
 typedef struct lrsc_kernel_stats {
     uint64_t launches;          /* launches since the last reset                        */

@@ -82,6 +82,12 @@ class WalkResult(C.Structure):
     _fields_ = [("code", C.c_int32), ("steps", C.c_uint32), ("out_off", C.c_uint64), ("out_len", C.c_uint32), ("pad", C.c_uint32)]
 
 
+class ReadResult(C.Structure):
+    _fields_ = [("merge", C.c_int32), ("n_pieces", C.c_uint32), ("piece_first", C.c_uint64)] + [
+        (n, C.c_int64) for n in ("total_reads_len", "corrected_len", "total_seed_num", "total_walk_num", "high_error_num",
+                                 "exceed_depth_num", "exceed_leave_num", "fm_num", "dp_num", "seed_dis")]
+
+
 class KernelStats(C.Structure):
     _fields_ = [
         ("launches", C.c_uint64),
@@ -163,6 +169,9 @@ class Lrsc:
                                       C.POINTER(C.c_uint64), C.c_void_p]
         L.lrsc_extend_walks.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                         C.c_uint64, C.POINTER(C.c_uint64)]
+        L.lrsc_correct_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64,
+                                         C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.lrsc_ctx_get_params.argtypes = [C.c_void_p, C.POINTER(Params)]
         L.lrsc_debug_sort_order.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         L.lrsc_ctx_stats.argtypes = [C.c_void_p, C.c_int, C.POINTER(KernelStats)]
         L.lrsc_ctx_stats_reset.argtypes = [C.c_void_p]
@@ -347,6 +356,30 @@ class Ctx:
             break
         raw = arena.raw
         return [(r.code, raw[r.out_off: r.out_off + r.out_len].decode() if r.code > 0 else "", r.steps) for r in res]
+
+    def correct_reads(self, bases: np.ndarray, off: np.ndarray):
+        """The whole per-read path.  -> (results: list[ReadResult], pieces: list[list[str]])."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        n = off.size - 1
+        res = (ReadResult * n)()
+        pcap, ocap = 2 * n + 16, int(off[-1]) * 2 + 4096
+        npieces, used = C.c_uint64(), C.c_uint64()
+        while True:
+            poff = np.zeros(pcap + 1, dtype=np.uint64)
+            out = np.zeros(ocap, dtype=np.uint8)
+            st = self.api.lib.lrsc_correct_reads(self.h, _ptr(bases), _ptr(off), n, res, _ptr(poff), pcap + 1, _ptr(out), ocap,
+                                                 C.byref(npieces), C.byref(used))
+            if st == -6:
+                pcap, ocap = max(pcap, int(npieces.value) + 1), max(ocap, int(used.value))
+                continue
+            self.api.check(st, "lrsc_correct_reads")
+            break
+        buf = out.tobytes()
+        pieces = []
+        for r in res:
+            pieces.append([buf[int(poff[p]): int(poff[p + 1])].decode() for p in range(r.piece_first, r.piece_first + r.n_pieces)])
+        return list(res), pieces
 
     def batch(self, bases: np.ndarray, off: np.ndarray) -> "Batch":
         bases = np.ascontiguousarray(bases, dtype=np.uint8)

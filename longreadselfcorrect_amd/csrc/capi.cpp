@@ -394,6 +394,13 @@ extern "C" void lrsc_ctx_destroy(lrsc_ctx* ctx)
     delete ctx;
 }
 
+extern "C" int lrsc_ctx_get_params(const lrsc_ctx* ctx, lrsc_params* out)
+{
+    if(!ctx || !out) return fail(LRSC_ERR_ARG, "null");
+    *out = ctx->params;
+    return LRSC_OK;
+}
+
 extern "C" int lrsc_ctx_sync(lrsc_ctx* ctx)
 {
     if(!ctx) return fail(LRSC_ERR_ARG, "null ctx");

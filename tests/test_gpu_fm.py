@@ -267,3 +267,48 @@ def test_extend_walks_match_oracle(api, gpu_index, oracle, small_ds, genome, cov
     assert codes.get(1, 0) > len(descs) // 2          # most walks succeed ...
     if (genome, cov) == (5, 90):
         assert codes.get(-1, 0) > 0                    # ... and the failure path is exercised too
+
+
+# ---- the whole per-read path (--nodp) ---------------------------------------------------------------------
+def _fasta(results, pieces, reads, split):
+    correct, discard = [], []
+    for r, (res, ps) in enumerate(zip(results, pieces)):
+        if res.merge:
+            for i, p in enumerate(ps):
+                correct.append(f">r{r}{'_' + str(i) if split else ''}\n{p}\n")
+        else:
+            discard.append(f">r{r}\n{reads[r]}\n")
+    return "".join(correct), "".join(discard)
+
+
+@pytest.mark.parametrize("genome,cov,split", [(5, 90, 0), (5, 90, 1), (10, 90, 0)])
+def test_whole_path_nodp_matches_oracle_fasta(api, gpu_index, oracle, small_ds, genome, cov, split):
+    """correct.fa / discard.fa and every integer counter of PacBioSelfCorrectionResult, bit-identical to the
+    CPU oracle (--nodp: failed walks copy the raw segment, PacBioSelfCorrectionProcess.cpp:146-147)."""
+    p = api.params_default(genome, cov)
+    p.no_dp, p.split = 1, split
+    ob, orb = oracle.bwt_load(small_ds.prefix + ".bwt"), oracle.bwt_load(small_ds.prefix + ".rbwt")
+    want = oracle.correct_reads(ob, orb, p, small_ds.bases, small_ds.off)
+    ctx = gpu_index.ctx(p, 0)
+    results, pieces = ctx.correct_reads(small_ds.bases, small_ds.off)
+    ctx.close()
+    cfa, dfa = _fasta(results, pieces, small_ds.reads, split)
+    assert cfa == want.correct_fa
+    assert dfa == want.discard_fa
+    names = ("total_reads_len", "corrected_len", "total_seed_num", "total_walk_num", "high_error_num", "exceed_depth_num",
+             "exceed_leave_num", "fm_num", "dp_num", "seed_dis", "merge")
+    got = np.array([[getattr(r, n) for n in names] for r in results], dtype=np.int64)
+    np.testing.assert_array_equal(got, want.counters)
+    assert got[:, 7].sum() > 500 and (got[:, 4].sum() + got[:, 5].sum()) > 0      # many FM walks, some failures
+    want.close(); ob.close(); orb.close()
+
+
+def test_dp_mode_is_refused_not_faked(api, gpu_index, small_ds):
+    from longreadselfcorrect_amd import LrscError
+
+    p = api.params_default(5, 90)            # no_dp = 0: needs the DP/MSA fallback
+    ctx = gpu_index.ctx(p, 0)
+    with pytest.raises(LrscError) as ei:
+        ctx.correct_reads(small_ds.bases[: int(small_ds.off[2])], small_ds.off[:3].copy())
+    assert ei.value.status == -7
+    ctx.close()
