@@ -28,7 +28,7 @@
 
 namespace lrsc {
 
-constexpr uint32_t kWalksPerWave = 16;
+constexpr uint32_t kWalksPerWave = 64;
 constexpr uint64_t kNoKey = ~0ull;
 
 // ---------------------------------------------------------------------------------------
@@ -673,7 +673,7 @@ struct Walk {
 };
 
 template <bool WIDE>
-__global__ __launch_bounds__(64) void walk_extend_kernel(FmIndexDev fm, ExtendArgs a)
+__global__ __launch_bounds__(64, 2) void walk_extend_kernel(FmIndexDev fm, ExtendArgs a)
 {
     using P = typename Lay<WIDE>::pos_t;
     __shared__ __attribute__((aligned(16))) uint32_t mtab[MaskTabSize<WIDE>::value];

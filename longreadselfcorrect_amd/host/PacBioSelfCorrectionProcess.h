@@ -1,0 +1,59 @@
+// PacBioSelfCorrectionProcess.h -- host-side mirror of the reference's processor / post-processor pair
+// (PacBio/PacBioSelfCorrectionProcess.h:24-127) over the C ABI (include/lrsc.h).
+#pragma once
+#include <cstdint>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "../../include/lrsc.h"
+#include "SequenceWorkItem.h"
+
+namespace stride {
+
+// PacBioSelfCorrectionParameters (reference .h:24-53): the index set becomes an lrsc_index + devices
+struct PacBioSelfCorrectionParameters {
+    lrsc_index* index = nullptr;
+    std::vector<int> devices{0};
+    std::string directory;
+    lrsc_params p{};                // PBcoverage, ErrorRate, startKmerLen, nextTarget, maxLeaves, idmerLen, minKmerLen, Split, NoDp ...
+    bool DebugExtend = false, DebugSeed = false, OnlySeed = false;
+};
+
+// PacBioSelfCorrectionResult (reference .h:58-94)
+struct PacBioSelfCorrectionResult {
+    std::string readid;
+    bool merge = false;
+    std::vector<std::string> correctedStrs;
+    int64_t totalReadsLen = 0, correctedLen = 0, totalSeedNum = 0, totalWalkNum = 0, highErrorNum = 0, exceedDepthNum = 0,
+            exceedLeaveNum = 0, FMNum = 0, DPNum = 0, seedDis = 0;
+    double Timer_Seed = 0, Timer_FM = 0, Timer_DP = 0;
+};
+
+// Batched processor: one lrsc_ctx per device, contiguous chunks of the batch per device.
+class PacBioSelfCorrectionProcess {
+public:
+    explicit PacBioSelfCorrectionProcess(const PacBioSelfCorrectionParameters& params);
+    ~PacBioSelfCorrectionProcess();
+    std::vector<PacBioSelfCorrectionResult> process_batch(const std::vector<SequenceWorkItem>& items);
+    PacBioSelfCorrectionResult process(const SequenceWorkItem& item);     // classic concept (one-item batch)
+private:
+    const PacBioSelfCorrectionParameters m_params;
+    std::vector<lrsc_ctx*> m_ctx;
+};
+
+// PacBioSelfCorrectionPostProcess (reference .cpp:250-380): correct.fa / discard.fa + the stats block
+class PacBioSelfCorrectionPostProcess {
+public:
+    explicit PacBioSelfCorrectionPostProcess(const PacBioSelfCorrectionParameters& params);
+    ~PacBioSelfCorrectionPostProcess();
+    void process(const SequenceWorkItem& workItem, const PacBioSelfCorrectionResult& result);
+private:
+    const PacBioSelfCorrectionParameters m_params;
+    std::ofstream m_correct, m_discard;
+    int64_t m_totalReadsLen = 0, m_correctedLen = 0, m_totalSeedNum = 0, m_totalWalkNum = 0, m_highErrorNum = 0,
+            m_exceedDepthNum = 0, m_exceedLeaveNum = 0, m_FMNum = 0, m_DPNum = 0, m_OutcastNum = 0, m_seedDis = 0;
+    double m_Timer_Seed = 0, m_Timer_FM = 0, m_Timer_DP = 0;
+};
+
+} // namespace stride
