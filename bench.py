@@ -65,6 +65,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from longreadselfcorrect_amd import Lrsc
+    from longreadselfcorrect_amd import dist as lrdist
     from longreadselfcorrect_amd.capi import K_GRID, K_SEEDS
 
     api = Lrsc()
@@ -92,7 +93,8 @@ def main():
     if rank == 0:
         bases, off = idx_bases, idx_off          # self-correction: rank 0 corrects the indexed reads themselves
     else:
-        bases, off = api.synth_reads(0x5EED0002, genome, n_reads, args.read_len, first_read=rank * n_reads)
+        bases, off = api.synth_reads(0x5EED0002, genome, n_reads, args.read_len,
+                                     first_read=lrdist.weak_shard_first_read(rank, n_reads))
     batch = ctx.batch(bases, off)
     my_bases = int(off[-1])
     log(f"batch resident in HBM: {my_bases / 1e6:.1f} Mbases")
@@ -107,8 +109,7 @@ def main():
     def fence():
         ctx.sync()
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        lrdist.barrier()
         torch.cuda.synchronize()
 
     fence()
@@ -119,13 +120,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     # max over ranks of the elapsed time; sum over ranks of the bases processed
-    tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    bb = torch.tensor([float(my_bases)], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dist.all_reduce(bb, op=dist.ReduceOp.SUM)
-    elapsed_max = float(tt.item())
-    total_bases = float(bb.item())
+    elapsed_max, total_bases = lrdist.combine(elapsed, float(my_bases), device="cuda")
 
     st = ctx.stats(K_GRID)
     st_seeds = ctx.stats(K_SEEDS)
