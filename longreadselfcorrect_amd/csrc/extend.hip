@@ -65,8 +65,16 @@ __global__ __launch_bounds__(256) void walk_prepare_kernel(FmIndexDev fm, Extend
     if(want_term) kmax = mink > kmax ? mink : kmax;
 
     WalkState<P> st = walk_init<P>();
-    for(uint32_t s = 0; s < kmax; ++s) {
-        st = walk_step<WIDE>(sf, sr, q[i + s], 1u << 30, st, mtab);     // findInterval semantics, early exit per strand
+    uint32_t n_rank_acc = 0, n_blk_acc = 0;
+    for(uint32_t s = 0; s < kmax;) {
+        // jump to the next emission size through a k-mer table when one of exactly that size exists
+        const uint32_t next_emit = s < 5 ? 5u : s < seedk ? seedk : mink;
+        if(!WIDE && next_emit <= kmax) {
+            WalkState<P> ts = walk_init<P>();
+            const uint32_t tk = table_start<WIDE>(fm, [&](uint32_t t) { return (uint32_t)q[i + t]; }, next_emit, ts);
+            if(tk == next_emit) { n_rank_acc += st.n_rank; n_blk_acc += st.n_blk; st = ts; st.n_rank = 0; st.n_blk = 0; s = tk; }
+            else { st = walk_step<WIDE>(sf, sr, q[i + s], 1u << 30, st, mtab); ++s; }
+        } else { st = walk_step<WIDE>(sf, sr, q[i + s], 1u << 30, st, mtab); ++s; }     // findInterval semantics, early exit per strand
         if(st.size == 5) flags5[i] = (uint8_t)((st.fwd.lo <= st.fwd.hi ? 1 : 0) | (st.rvc.lo <= st.rvc.hi ? 2 : 0));
         if(st.size == seedk) {
             it9f[i].key = st.fwd.lo <= st.fwd.hi ? (uint64_t)st.fwd.lo : kNoKey; it9f[i].val = i; it9f[i].pad = 0;
@@ -78,8 +86,8 @@ __global__ __launch_bounds__(256) void walk_prepare_kernel(FmIndexDev fm, Extend
         }
     }
     if(a.ctr) {
-        atomicAdd(&a.ctr->rank_queries, (unsigned long long)st.n_rank);
-        atomicAdd(&a.ctr->block_loads, (unsigned long long)st.n_blk);
+        atomicAdd(&a.ctr->rank_queries, (unsigned long long)(st.n_rank + n_rank_acc));
+        atomicAdd(&a.ctr->block_loads, (unsigned long long)(st.n_blk + n_blk_acc));
     }
 }
 
@@ -131,6 +139,7 @@ struct Walk {
     using P = typename Lay<WIDE>::pos_t;
     // index
     StrandC<P> sF, sR;
+    const FmIndexDev* fm;
     const uint32_t* mtab;
     // inputs
     const uint8_t* q;                 // m_query codes
@@ -171,7 +180,8 @@ struct Walk {
     __device__ void find_suffix(Leaf<P>& lf, uint32_t l)
     {
         WalkState<P> st = walk_init<P>();
-        for(uint32_t t = 0; t < l; ++t) {
+        const uint32_t t0 = table_start<WIDE>(*fm, [&](uint32_t t) { return suf_char(lf, l, t); }, l, st);
+        for(uint32_t t = t0; t < l; ++t) {
             if(st.fwd_broken && st.rvc_broken) break;
             st = walk_step<WIDE>(sF, sR, suf_char(lf, l, t), 1u << 30, st, mtab);
         }
@@ -688,6 +698,7 @@ __global__ __launch_bounds__(64, 2) void walk_extend_kernel(FmIndexDev fm, Exten
         Walk<WIDE> W;
         W.sF = strand_consts<P>(fm.strand[LRSC_RBWT]);
         W.sR = strand_consts<P>(fm.strand[LRSC_BWT]);
+        W.fm = &fm;
         W.mtab = mtab;
         W.q = a.codes + ww.codes_off;
         W.Lq = ww.lq; W.initk = ww.initk; W.path_len = ww.path_len; W.trg_len = ww.trg_len; W.dis = ww.dis;

@@ -57,9 +57,20 @@ struct FmStrand {
     uint64_t n_blocks;
     uint64_t pred[5];            // C[$ACGT]
 };
+// k-mer interval tables (device-side BWTIntervalCache, SuffixTools/BWTIntervalCache.h:24-29 -- the
+// reference has the class but pbcorrect leaves it unused): entry[code(w)] = {fwd.lo, fwd.hi, rvc.lo, rvc.hi}
+// of findBiInterval(w) INCLUDING findInterval's early exit, i.e. exactly the state after the first k
+// steps of a search.  Narrow (32-bit) indexes only.  Up to three sizes, ascending.
+struct KmerTable {
+    const void* entries;         // uint4[4^k]
+    uint32_t k;                  // 0 = absent
+    uint32_t pad;
+};
 struct FmIndexDev {
     FmStrand strand[2];          // [LRSC_BWT], [LRSC_RBWT]
     uint32_t wide;               // 0 -> Block32, 1 -> Block64
+    uint32_t pad;
+    KmerTable ktab[3];
 };
 
 // mask of the low n bits of a 32-symbol word, n clamped to [0, 32]

@@ -140,7 +140,27 @@ __global__ __launch_bounds__(256) void kmer_grid_kernel(FmIndexDev fm, GridArgs 
             if(a.slot_iv) a.slot_iv[(uint64_t)j * a.total_bases + gid] = to_out(st.fwd, st.rvc);
         };
 
-        for(uint32_t s = 0; s < avail; ++s) {
+        // Compact mode: only frequency / validity / the base-search counter are emitted, so the first T steps
+        // can come from the k-mer table when both strands are still valid after them (then no early exit
+        // happened, the chained expand() state equals the plain search, and the base counter is base_k).
+        uint32_t s0 = 0;
+        if(!WIDE && !a.out_iv && !a.out_size && !a.out_count && !a.slot_iv) {
+            WalkState<P> ts = st;
+            const uint32_t tk = table_start<WIDE>(fm, [&](uint32_t t) { return (uint32_t)w[t]; }, avail, ts);
+            if(tk >= base_k && !ts.fwd_broken && !ts.rvc_broken) {
+                // slots below the table size are not stored in compact mode (freq_index < 0): check, else fall back
+                bool ok = true;
+                for(uint32_t j = 0; j < a.n_k && a.ks[j] < tk; ++j) ok = ok && (a.freq_index[j] < 0);
+                if(ok) {
+                    st = ts; st.counted = base_k; st.n_rank = 0; st.n_blk = 0;
+                    s0 = tk;
+                    while(slot < a.n_k && a.ks[slot] < tk) ++slot;
+                    next_k = slot < a.n_k ? a.ks[slot] : 0xFFFFFFFFu;
+                    if(st.size == next_k) { emit(slot); ++slot; next_k = slot < a.n_k ? a.ks[slot] : 0xFFFFFFFFu; }
+                }
+            }
+        }
+        for(uint32_t s = s0; s < avail; ++s) {
             st = walk_step<WIDE>(sf, sr, w[s], base_k, st, mtab);
             if(st.size == next_k) {
                 emit(slot);
@@ -155,6 +175,25 @@ __global__ __launch_bounds__(256) void kmer_grid_kernel(FmIndexDev fm, GridArgs 
         n_rank = st.n_rank; n_blk = st.n_blk;
     }
     flush_counters(ctr, n_rank, n_blk);
+}
+
+// every k-mer's findBiInterval (with early exit) -> table entry; narrow layout only
+__global__ __launch_bounds__(256) void ktab_build_kernel(FmIndexDev fm, uint32_t k, uint4* __restrict__ entries)
+{
+    using P = uint32_t;
+    __shared__ __attribute__((aligned(16))) uint32_t mtab[MaskTabSize<false>::value];
+    init_mask_table<false>(mtab);
+    const uint64_t code = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if(code >= (1ull << (2 * k))) return;
+    const StrandC<P> sf = strand_consts<P>(fm.strand[LRSC_RBWT]);
+    const StrandC<P> sr = strand_consts<P>(fm.strand[LRSC_BWT]);
+    WalkState<P> st = walk_init<P>();
+    for(uint32_t t = 0; t < k; ++t) {
+        if(st.fwd_broken && st.rvc_broken) break;
+        const uint32_t c = (uint32_t)(code >> (2 * (k - 1 - t))) & 3u;
+        st = walk_step<false>(sf, sr, c, 1u << 30, st, mtab);
+    }
+    entries[code] = make_uint4(st.fwd.lo, st.fwd.hi, st.rvc.lo, st.rvc.hi);
 }
 
 __global__ __launch_bounds__(256) void encode_kernel(const char* __restrict__ ascii, uint8_t* __restrict__ codes,
@@ -222,6 +261,14 @@ hipError_t launch_kmer_grid(const FmIndexDev& fm, const GridArgs& a, DevCounters
     if(a.total_bases == 0) return hipSuccess;
     if(fm.wide) hipLaunchKernelGGL(kmer_grid_kernel<true>, dim3(blocks_for(a.total_bases)), dim3(256), 0, stream, fm, a, ctr);
     else        hipLaunchKernelGGL(kmer_grid_kernel<false>, dim3(blocks_for(a.total_bases)), dim3(256), 0, stream, fm, a, ctr);
+    return hipGetLastError();
+}
+
+hipError_t launch_ktab_build(const FmIndexDev& fm, uint32_t k, void* entries, hipStream_t stream)
+{
+    if(fm.wide || k == 0 || k > 15) return hipErrorInvalidValue;
+    const uint64_t n = 1ull << (2 * k);
+    hipLaunchKernelGGL(ktab_build_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, fm, k, reinterpret_cast<uint4*>(entries));
     return hipGetLastError();
 }
 

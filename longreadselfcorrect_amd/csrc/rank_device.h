@@ -287,6 +287,35 @@ walk_step(const StrandC<typename Lay<WIDE>::pos_t>& sf, const StrandC<typename L
     return st;
 }
 
+// ---------------------------------------------------------------------------------------
+// k-mer table start: the state of a findInterval-semantics walk (walk_step with base_k = inf) after its
+// first k characters, from one 16-byte load.  get(t) returns the t-th character code of the sequence.
+// Returns 0 (and leaves st untouched) when no table of size <= max_k exists.
+// ---------------------------------------------------------------------------------------
+template <bool WIDE, class Get>
+__device__ __forceinline__ uint32_t table_start(const FmIndexDev& fm, Get get, uint32_t max_k,
+                                                WalkState<typename Lay<WIDE>::pos_t>& st)
+{
+    if(WIDE) return 0;
+    using P = typename Lay<WIDE>::pos_t;
+    int best = -1;
+    if(fm.ktab[0].k != 0 && fm.ktab[0].k <= max_k) best = 0;
+    if(fm.ktab[1].k != 0 && fm.ktab[1].k <= max_k) best = 1;
+    if(fm.ktab[2].k != 0 && fm.ktab[2].k <= max_k) best = 2;
+    if(best < 0) return 0;
+    const uint32_t k = best == 0 ? fm.ktab[0].k : best == 1 ? fm.ktab[1].k : fm.ktab[2].k;
+    const uint4* tab = reinterpret_cast<const uint4*>(best == 0 ? fm.ktab[0].entries : best == 1 ? fm.ktab[1].entries : fm.ktab[2].entries);
+    uint32_t code = 0;
+    for(uint32_t t = 0; t < k; ++t) code = (code << 2) | get(t);
+    const uint4 e = tab[code];
+    st.fwd.lo = (P)e.x; st.fwd.hi = (P)e.y; st.rvc.lo = (P)e.z; st.rvc.hi = (P)e.w;
+    st.fwd_broken = e.x > e.y;
+    st.rvc_broken = e.z > e.w;
+    st.size = k;
+    st.counted = k;          // only meaningful when !fwd_broken (callers that need the exact count fall back)
+    return k;
+}
+
 template <class P> __device__ __forceinline__ int64_t iv_freq(const IvT<P>& iv) { return iv.lo <= iv.hi ? (int64_t)(iv.hi - iv.lo) + 1 : 0; }
 template <class P> __device__ __forceinline__ lrsc_biinterval to_out(const IvT<P>& f, const IvT<P>& r)
 {

@@ -164,10 +164,21 @@ def _seed_case(api, gpu_index, oracle, small_ds, params, bases, off):
     return wcount, wseeds, wattr
 
 
-@pytest.fixture(scope="module")
-def gpu_index(api, small_ds):
+@pytest.fixture(scope="module", params=["default", "11", "0"], ids=["ktab-default", "ktab-11", "ktab-off"])
+def gpu_index(request, api, small_ds):
+    """The same index with the k-mer interval tables at their default size, forced to T = 11, and disabled:
+    every parity test below runs against all three (results must not depend on the tables)."""
+    import os
+
+    old = os.environ.get("LRSC_KTAB_K")
+    if request.param != "default":
+        os.environ["LRSC_KTAB_K"] = request.param
     idx = api.index_open(small_ds.prefix + ".bwt", small_ds.prefix + ".rbwt")
     idx.upload(0)
+    if old is None:
+        os.environ.pop("LRSC_KTAB_K", None)
+    else:
+        os.environ["LRSC_KTAB_K"] = old
     yield idx
     idx.close()
 
