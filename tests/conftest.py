@@ -77,3 +77,29 @@ def write_fasta(path, reads, prefix="r"):
     with open(path, "w") as f:
         for i, r in enumerate(reads):
             f.write(f">{prefix}{i}\n{r}\n")
+
+
+class RepeatDataset(Dataset):
+    """Like Dataset, but the genome carries a 75-copy interspersed repeat (60-bp unit + 20-bp unique spacers) and
+    a 6-copy 350-bp repeat, so that repeat-mode attributes (19-mers above the ~640x repeat threshold at 90x),
+    isRepeat seeds and repeat-to-unique (reverse strand) walks occur."""
+
+    def __init__(self, api, oracle, tmp, seed=0xBEEF):
+        g = api.synth_genome(seed, 14000).copy()
+        unit = g[50:110].copy()
+        for c in range(75):
+            pos = 4000 + c * 80
+            g[pos: pos + 60] = unit
+        seg1 = g[300:650].copy()
+        for pos in (1200, 2100, 3000, 10500, 12000):
+            g[pos: pos + 350] = seg1
+        self.genome = g
+        self.n_reads = 630
+        self.bases, self.off = api.synth_reads(seed + 1, g, self.n_reads, 2000)
+        self.prefix = str(Path(tmp) / "rep")
+        oracle.build_index(self.bases, self.off, self.prefix)
+
+
+@pytest.fixture(scope="session")
+def repeat_ds(api, oracle, tmp_path_factory):
+    return RepeatDataset(api, oracle, tmp_path_factory.mktemp("repeat_ds"))

@@ -323,3 +323,55 @@ def test_dp_mode_is_refused_not_faked(api, gpu_index, small_ds):
         ctx.correct_reads(small_ds.bases[: int(small_ds.off[2])], small_ds.off[:3].copy())
     assert ei.value.status == -7
     ctx.close()
+
+
+# ---- repeat-rich data: mode-2 attributes, isRepeat seeds, repeat-to-unique (reverse-strand) walks ---------------
+@pytest.fixture(scope="module")
+def rep_index(api, repeat_ds):
+    idx = api.index_open(repeat_ds.prefix + ".bwt", repeat_ds.prefix + ".rbwt")
+    idx.upload(0)
+    yield idx
+    idx.close()
+
+
+@pytest.mark.parametrize("genome", [5, 10])
+def test_repeat_dataset_seeds_walks_and_fasta(api, rep_index, oracle, repeat_ds, genome):
+    p = api.params_default(genome, 90)
+    p.no_dp = 1
+    ob, orb = oracle.bwt_load(repeat_ds.prefix + ".bwt"), oracle.bwt_load(repeat_ds.prefix + ".rbwt")
+    n_reads = 200
+    off = repeat_ds.off[: n_reads + 1].copy()
+    bases = repeat_ds.bases[: int(off[-1])]
+    # seeds + attribute
+    ctx = rep_index.ctx(p, 0)
+    b = ctx.batch(bases, off)
+    b.find_seeds()
+    count, seeds, attr = b.seeds()
+    b.close()
+    wcount, wseeds, wattr = oracle.find_seeds(ob, orb, p, bases, off)
+    np.testing.assert_array_equal(attr, wattr)
+    np.testing.assert_array_equal(count, wcount)
+    np.testing.assert_array_equal(np.stack([seeds[f] for f in seeds.dtype.names], axis=1), wseeds)
+    assert (wattr == 2).mean() > 0.01 and wseeds[:, 3].sum() > 5           # repeat mode + repeat seeds really occur
+    # walks, including the reversed ones
+    reads = repeat_ds.reads[:n_reads]
+    descs = _walk_descs(p, reads, wcount, wseeds)
+    n_rtou = 0
+    k = 0
+    for r, n in enumerate(wcount):
+        ss = wseeds[k: k + n]; k += n
+        n_rtou += int(sum(1 for i in range(max(int(n) - 1, 0)) if ss[i][3] and not ss[i + 1][3]))
+    assert n_rtou >= 1
+    got = ctx.extend_walks(descs)
+    for d, (code, merged, steps) in zip(descs, got):
+        wcode, wmerged, wst = oracle.extend_walk(ob, orb, p, *d)
+        assert (code, merged, steps) == (wcode, wmerged, wst[0]), d
+    # whole path
+    want = oracle.correct_reads(ob, orb, p, bases, off)
+    results, pieces = ctx.correct_reads(bases, off)
+    cfa, dfa = _fasta(results, pieces, reads, 0)
+    assert cfa == want.correct_fa and dfa == want.discard_fa
+    names = ("total_reads_len", "corrected_len", "total_seed_num", "total_walk_num", "high_error_num", "exceed_depth_num",
+             "exceed_leave_num", "fm_num", "dp_num", "seed_dis", "merge")
+    np.testing.assert_array_equal(np.array([[getattr(r, n) for n in names] for r in results], dtype=np.int64), want.counters)
+    ctx.close(); want.close(); ob.close(); orb.close()
