@@ -125,12 +125,14 @@ def main():
     st = ctx.stats(K_GRID)
     st_seeds = ctx.stats(K_SEEDS)
     kernel_ms = st.total_ms / max(st.launches, 1)
-    achieved = (st.block_loads / max(st.launches, 1)) * BLOCK_BYTES / (kernel_ms * 1e-3) / 1e9
+    # algorithmic 64-byte lines per launch: rank blocks + k-mer-table entries (one line each)
+    lines_per_launch = (st.block_loads + st.table_loads) / max(st.launches, 1)
+    achieved = lines_per_launch * BLOCK_BYTES / (kernel_ms * 1e-3) / 1e9
 
     # HBM-side traffic of the same kernel on the same workload comes from the committed rocprofv3 --pmc
     # pass (it cannot be sampled from inside the process); null for any other workload.
     traffic, traffic_src = None, None
-    pmc = REPO / "profiles" / "r01_pmc" / "traffic.json"
+    pmc = REPO / "profiles" / "r01_pmc" / "traffic_v5.json"
     if pmc.exists() and n_reads == 100_000 and abs(args.genome_mb - 11.1) < 1e-9 and args.read_len == 10_000:
         pj = json.loads(pmc.read_text())
         traffic, traffic_src = pj["traffic_bytes_per_launch"] / 1e9, pj["source"]
@@ -172,7 +174,8 @@ def main():
                 "traffic": traffic,
                 "traffic_unit": "GB per launch (FETCH_SIZE x 1024, separate --pmc pass)",
                 "traffic_source": traffic_src,
-                "algorithmic_gb_per_launch": st.block_loads / max(st.launches, 1) * BLOCK_BYTES / 1e9,
+                "algorithmic_gb_per_launch": lines_per_launch * BLOCK_BYTES / 1e9,
+                "table_loads_per_launch": st.table_loads / max(st.launches, 1),
                 "kernel_ms": kernel_ms,
                 "block_loads_per_launch": st.block_loads / max(st.launches, 1),
                 "rank_queries_per_launch": st.rank_queries / max(st.launches, 1),

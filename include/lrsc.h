@@ -244,14 +244,22 @@ int lrsc_correct_reads(lrsc_ctx* ctx, const char* reads, const uint64_t* read_of
                        uint64_t* n_pieces, uint64_t* out_used);
 int lrsc_ctx_get_params(const lrsc_ctx* ctx, lrsc_params* out);
 
+/* ---- DP/MSA fallback building blocks ------------------------------------------------------------------- */
+/* LongReadOverlap::retrieveStr's LF-walks (PacBio/LongReadOverlap.cpp:696-749): job i starts at BWT row
+ * rows[i] of strand[i] and emits at most max_steps[i] characters (stops at a '$' row).  Job i's characters
+ * ("ACGT", in walk order) land at out + out_off[i]; out_len[i] receives how many. */
+int lrsc_lf_walk(lrsc_ctx* ctx, const uint64_t* rows, const uint8_t* strand, const uint32_t* max_steps,
+                 const uint64_t* out_off, uint64_t n, char* out, uint64_t out_cap, uint32_t* out_len);
+
 /* ---- measurement ------------------------------------------------------------------------- */
 typedef struct lrsc_kernel_stats {
     uint64_t launches;          /* launches since the last reset                        */
     double   total_ms;          /* sum of HIP-event durations on the ctx stream          */
     uint64_t rank_queries;      /* Occ queries issued (algorithmic count)                */
     uint64_t block_loads;       /* rank-block loads (lower-1/upper in one block count 1) */
+    uint64_t table_loads;       /* k-mer interval table look-ups (one 64-byte line each)  */
 } lrsc_kernel_stats;
-enum { LRSC_K_RANK = 0, LRSC_K_FIND = 1, LRSC_K_GRID = 2, LRSC_K_SEEDS = 3, LRSC_K_EXTEND = 4, LRSC_K_COUNT = 5 };
+enum { LRSC_K_RANK = 0, LRSC_K_FIND = 1, LRSC_K_GRID = 2, LRSC_K_SEEDS = 3, LRSC_K_EXTEND = 4, LRSC_K_LF = 5, LRSC_K_COUNT = 6 };
 int lrsc_ctx_stats(lrsc_ctx* ctx, int kernel, lrsc_kernel_stats* out);
 int lrsc_ctx_stats_reset(lrsc_ctx* ctx);
 /* Block until everything queued on the ctx stream is done. */

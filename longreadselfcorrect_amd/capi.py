@@ -94,10 +94,11 @@ class KernelStats(C.Structure):
         ("total_ms", C.c_double),
         ("rank_queries", C.c_uint64),
         ("block_loads", C.c_uint64),
+        ("table_loads", C.c_uint64),
     ]
 
 
-K_RANK, K_FIND, K_GRID, K_SEEDS, K_EXTEND = range(5)
+K_RANK, K_FIND, K_GRID, K_SEEDS, K_EXTEND, K_LF = range(6)
 SEED_DTYPE = np.dtype([("start", "<i4"), ("len", "<i4"), ("max_freq", "<i4"), ("repeat", "<i4"), ("start_k", "<i4"),
                        ("end_k", "<i4"), ("start_freq", "<i4"), ("end_freq", "<i4")])
 BWT, RBWT = 0, 1
@@ -172,6 +173,8 @@ class Lrsc:
         L.lrsc_correct_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64,
                                          C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.lrsc_ctx_get_params.argtypes = [C.c_void_p, C.POINTER(Params)]
+        L.lrsc_lf_walk.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                   C.c_void_p]
         L.lrsc_debug_sort_order.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         L.lrsc_ctx_stats.argtypes = [C.c_void_p, C.c_int, C.POINTER(KernelStats)]
         L.lrsc_ctx_stats_reset.argtypes = [C.c_void_p]
@@ -330,6 +333,20 @@ class Ctx:
         return (iv.reshape(shape) if iv is not None else None,
                 size.reshape(shape) if size is not None else None,
                 cnt.reshape(shape + (4,)) if cnt is not None else None)
+
+    def lf_walk(self, rows, strand, max_steps) -> list[str]:
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        strand = np.ascontiguousarray(strand, dtype=np.uint8)
+        max_steps = np.ascontiguousarray(max_steps, dtype=np.uint32)
+        off = np.zeros(rows.size, dtype=np.uint64)
+        off[1:] = np.cumsum(max_steps[:-1].astype(np.uint64))
+        cap = int(max_steps.astype(np.uint64).sum()) + 1
+        out = np.zeros(cap, dtype=np.uint8)
+        lens = np.zeros(rows.size, dtype=np.uint32)
+        self.api.check(self.api.lib.lrsc_lf_walk(self.h, _ptr(rows), _ptr(strand), _ptr(max_steps), _ptr(off), rows.size, _ptr(out), cap,
+                                                 _ptr(lens)), "lrsc_lf_walk")
+        buf = out.tobytes()
+        return [buf[int(off[i]): int(off[i]) + int(lens[i])].decode() for i in range(rows.size)]
 
     def extend_walks(self, walks):
         """walks: list of (src, path, trg, dis, init_kmer, max_overlap, min_sa).  -> list of (code, mergedSeq, steps)."""

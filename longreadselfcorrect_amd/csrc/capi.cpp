@@ -400,8 +400,8 @@ extern "C" int lrsc_ctx_create(const lrsc_index* idx, const lrsc_params* params,
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if(e == hipSuccess) e = hipEventCreate(&ctx->ev0);
     if(e == hipSuccess) e = hipEventCreate(&ctx->ev1);
-    if(e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_ctr), sizeof(DevCounters));
-    if(e == hipSuccess) e = hipMemset(ctx->d_ctr, 0, sizeof(DevCounters));
+    if(e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_ctr), kCtrShards * sizeof(DevCounters));
+    if(e == hipSuccess) e = hipMemset(ctx->d_ctr, 0, kCtrShards * sizeof(DevCounters));
     if(e != hipSuccess) { lrsc_ctx_destroy(ctx); return hip_fail(e, "lrsc_ctx_create"); }
     *out = ctx;
     return LRSC_OK;
@@ -439,7 +439,7 @@ extern "C" int lrsc_ctx_sync(lrsc_ctx* ctx)
 template <class F>
 static int timed_launch(lrsc_ctx* ctx, int which, F&& launch)
 {
-    HIP_TRY(hipMemsetAsync(ctx->d_ctr, 0, sizeof(DevCounters), ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_ctr, 0, kCtrShards * sizeof(DevCounters), ctx->stream));
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
     hipError_t e = launch();
     if(e != hipSuccess) return hip_fail(e, "kernel launch");
@@ -447,13 +447,16 @@ static int timed_launch(lrsc_ctx* ctx, int which, F&& launch)
     HIP_TRY(hipEventSynchronize(ctx->ev1));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    std::vector<DevCounters> shards(kCtrShards);
+    HIP_TRY(hipMemcpy(shards.data(), ctx->d_ctr, kCtrShards * sizeof(DevCounters), hipMemcpyDeviceToHost));
     DevCounters h{};
-    HIP_TRY(hipMemcpy(&h, ctx->d_ctr, sizeof(h), hipMemcpyDeviceToHost));
+    for(const DevCounters& d : shards) { h.rank_queries += d.rank_queries; h.block_loads += d.block_loads; h.table_loads += d.table_loads; }
     lrsc_kernel_stats& s = ctx->stats[which];
     s.launches += 1;
     s.total_ms += ms;
     s.rank_queries += h.rank_queries;
     s.block_loads += h.block_loads;
+    s.table_loads += h.table_loads;
     return LRSC_OK;
 }
 
@@ -512,6 +515,38 @@ extern "C" int lrsc_bwt_chars(lrsc_ctx* ctx, int strand, const uint64_t* idx, ui
     if(e != hipSuccess) return hip_fail(e, "bwt_chars");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipMemcpy(out, ctx->s_out.p, n, hipMemcpyDeviceToHost));
+    return LRSC_OK;
+}
+
+extern "C" int lrsc_lf_walk(lrsc_ctx* ctx, const uint64_t* rows, const uint8_t* strand, const uint32_t* max_steps,
+                            const uint64_t* out_off, uint64_t n, char* out, uint64_t out_cap, uint32_t* out_len)
+{
+    if(!ctx || ((!rows || !strand || !max_steps || !out_off || !out || !out_len) && n)) return fail(LRSC_ERR_ARG, "null");
+    if(n == 0) return LRSC_OK;
+    const uint64_t N = ctx->index->num_symbols;
+    std::vector<LfJob> jobs(n);
+    uint64_t need = 0;
+    for(uint64_t i = 0; i < n; ++i) {
+        if(rows[i] >= N || strand[i] > 1) return fail(LRSC_ERR_ARG, "LF job out of range");
+        jobs[i].row = rows[i]; jobs[i].out_off = out_off[i]; jobs[i].max_steps = max_steps[i]; jobs[i].strand = strand[i];
+        need = std::max(need, out_off[i] + max_steps[i]);
+    }
+    if(need > out_cap) return fail(LRSC_ERR_CAPACITY, "LF output buffer too small");
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevBuf<LfJob> d_jobs;
+    DevBuf<uint8_t> d_out;
+    DevBuf<uint32_t> d_len;
+    HIP_TRY(d_jobs.reserve(n));
+    HIP_TRY(d_out.reserve(std::max<uint64_t>(need, 1)));
+    HIP_TRY(d_len.reserve(n));
+    HIP_TRY(hipMemcpyAsync(d_jobs.p, jobs.data(), n * sizeof(LfJob), hipMemcpyHostToDevice, ctx->stream));
+    const int st = timed_launch(ctx, LRSC_K_LF, [&]() { return launch_lf_walk(ctx->fm, d_jobs.p, n, d_out.p, d_len.p, ctx->d_ctr, ctx->stream); });
+    if(st != LRSC_OK) return st;
+    HIP_TRY(hipMemcpy(out_len, d_len.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    std::vector<uint8_t> codes(need);
+    HIP_TRY(hipMemcpy(codes.data(), d_out.p, need, hipMemcpyDeviceToHost));
+    for(uint64_t i = 0; i < n; ++i)
+        for(uint32_t t = 0; t < out_len[i]; ++t) out[out_off[i] + t] = "ACGT"[codes[out_off[i] + t] & 3];
     return LRSC_OK;
 }
 
@@ -758,7 +793,14 @@ extern "C" int lrsc_batch_kmer_grid(lrsc_ctx* ctx, lrsc_batch* b)
     int st = batch_setup_rows(ctx, b);
     if(st != LRSC_OK) return st;
     const GridArgs a = batch_grid_args(b);
-    st = timed_launch(ctx, LRSC_K_GRID, [&]() { return launch_kmer_grid(ctx->fm, a, ctx->d_ctr, ctx->stream); });
+    // One lane per position is the default.  LRSC_GRID_MODE=quad selects the quad-cooperative kernel
+    // (grid_quad.hip), kept for experiments: on config[1] it is ~4x slower because it quarters the
+    // lines in flight per wavefront and this kernel is latency/MLP-bound (profiles/).
+    const char* mode = std::getenv("LRSC_GRID_MODE");
+    const bool quad = !ctx->fm.wide && mode && std::strcmp(mode, "quad") == 0;
+    st = timed_launch(ctx, LRSC_K_GRID, [&]() {
+        return quad ? launch_kmer_grid_quad(ctx->fm, a, ctx->d_ctr, ctx->stream) : launch_kmer_grid(ctx->fm, a, ctx->d_ctr, ctx->stream);
+    });
     if(st == LRSC_OK) b->grid_done = true;
     return st;
 }

@@ -41,7 +41,8 @@ __global__ __launch_bounds__(256) void walk_prepare_kernel(FmIndexDev fm, Extend
     __shared__ __attribute__((aligned(16))) uint32_t mtab[MaskTabSize<WIDE>::value];
     init_mask_table<WIDE>(mtab);
     const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if(gid >= a.total_q) return;
+    uint32_t cnt_rank = 0, cnt_blk = 0;
+    if(gid < a.total_q) {
     uint32_t w = a.chunk_walk[gid >> kChunkShift];
     while(a.q_off[w + 1] <= gid) ++w;
     const WalkWork ww = a.work[w];
@@ -85,10 +86,9 @@ __global__ __launch_bounds__(256) void walk_prepare_kernel(FmIndexDev fm, Extend
             t[0] = st.fwd.lo; t[1] = st.fwd.hi; t[2] = st.rvc.lo; t[3] = st.rvc.hi;
         }
     }
-    if(a.ctr) {
-        atomicAdd(&a.ctr->rank_queries, (unsigned long long)(st.n_rank + n_rank_acc));
-        atomicAdd(&a.ctr->block_loads, (unsigned long long)(st.n_blk + n_blk_acc));
+    cnt_rank = st.n_rank + n_rank_acc; cnt_blk = st.n_blk + n_blk_acc;
     }
+    flush_counters(a.ctr, cnt_rank, cnt_blk);
 }
 
 // ---------------------------------------------------------------------------------------

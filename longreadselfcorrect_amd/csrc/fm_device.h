@@ -6,8 +6,8 @@
 // 64-byte, 64-byte-aligned block holding cumulative counts and the symbols as two BIT PLANES:
 //
 //   Block32 (N < 2^31 symbols): 4 x u32 counts of A,C,G,T before the block
-//                               + lo[6] + hi[6] u32 = 192 symbols (bit i of lo[w]/hi[w] = low/high
-//                               code bit of symbol 32*w + i)
+//                               + 6 low-plane + 6 high-plane u32 = 192 symbols (bit i of plane word w =
+//                               low/high code bit of symbol 32*w + i), grouped into 16-byte pieces (below)
 //   Block64 (any N):            4 x u64 counts + lo[4] + hi[4] u32 = 128 symbols
 //
 // With planes, "symbols equal to code c among the first n" is popcount((lo ^ L) & (hi ^ H) & mask)
@@ -28,12 +28,18 @@
 
 namespace lrsc {
 
+// Block32 is organised as four 16-byte PIECES so that 4 lanes can fetch one block with one coalesced
+// 64-byte access and each lane owns a self-contained slice:
+//   piece 0:      cnt[4]
+//   piece j=1..3: { lo[2j-2], lo[2j-1], hi[2j-2], hi[2j-1] }  = both bit planes of symbols [64(j-1), 64j)
 struct alignas(64) Block32 {
     static constexpr uint32_t kSyms = 192;
     static constexpr uint32_t kWords = 6;
     uint32_t cnt[4];
-    uint32_t lo[6];
-    uint32_t hi[6];
+    uint32_t w[12];
+    // index into w[] of the low / high plane word holding symbols [32*wi, 32*wi + 32)
+    static constexpr uint32_t lo_index(uint32_t wi) { return (wi >> 1) * 4 + (wi & 1); }
+    static constexpr uint32_t hi_index(uint32_t wi) { return (wi >> 1) * 4 + 2 + (wi & 1); }
 };
 struct alignas(64) Block64 {
     static constexpr uint32_t kSyms = 128;

@@ -39,6 +39,17 @@ int read_bwt_file(const std::string& path, std::vector<uint8_t>& units, uint64_t
     return LRSC_OK;
 }
 
+static inline void set_symbol(Block32& b, unsigned off, unsigned code)
+{
+    b.w[Block32::lo_index(off >> 5)] |= (uint32_t)(code & 1u) << (off & 31u);
+    b.w[Block32::hi_index(off >> 5)] |= (uint32_t)(code >> 1) << (off & 31u);
+}
+static inline void set_symbol(Block64& b, unsigned off, unsigned code)
+{
+    b.lo[off >> 5] |= (uint32_t)(code & 1u) << (off & 31u);
+    b.hi[off >> 5] |= (uint32_t)(code >> 1) << (off & 31u);
+}
+
 template <class Block>
 static int build_image_t(const uint8_t* units, uint64_t n_units, uint64_t num_symbols,
                          StrandImage& out, std::string& err)
@@ -80,8 +91,7 @@ static int build_image_t(const uint8_t* units, uint64_t n_units, uint64_t num_sy
                 code = rank - 1;
                 ++counts[code];
             }
-            blk[b].lo[off >> 5] |= (uint32_t)(code & 1u) << (off & 31u);
-            blk[b].hi[off >> 5] |= (uint32_t)(code >> 1) << (off & 31u);
+            set_symbol(blk[b], off, code);
         }
     }
     if(pos != num_symbols) { err = "BWT runs do not add up to the symbol count in the header"; return LRSC_ERR_FORMAT; }

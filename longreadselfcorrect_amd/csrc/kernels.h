@@ -8,11 +8,16 @@
 
 namespace lrsc {
 
-// device-side counters filled by the kernels (one per ctx)
-struct DevCounters {
+// device-side counters filled by the kernels.  One ctx owns kCtrShards of them, each on its own 64-byte
+// line: every wavefront adds its totals to shard (blockIdx.x % kCtrShards).  (A single shared line was
+// measured to throttle the grid kernel: ~49 M same-line atomics per launch at ~88 atomics/us.)
+struct alignas(64) DevCounters {
     unsigned long long rank_queries;
     unsigned long long block_loads;
+    unsigned long long table_loads;     // k-mer interval table look-ups (16-byte entries, one 64-byte line each)
+    unsigned long long pad[5];
 };
+constexpr uint32_t kCtrShards = 1024;
 
 constexpr uint32_t kMaxPool = 8;
 constexpr uint32_t kChunkShift = 10;   // coarse position -> read table granularity (1024 bases)
@@ -76,11 +81,18 @@ hipError_t scan_seed_flags(unsigned long long* flags, uint32_t* zeros, uint64_t 
 hipError_t launch_ktab_build(const FmIndexDev& fm, uint32_t k, void* entries, hipStream_t stream);
 hipError_t launch_rank(const FmIndexDev& fm, const lrsc_rank_query* q, uint64_t n, uint64_t* out,
                        DevCounters* ctr, hipStream_t stream);
+// LF-walk (LongReadOverlap::retrieveStr, PacBio/LongReadOverlap.cpp:696-749): from BWT row `row` of `strand`,
+// b = BWT[idx]; stop at '$' or after max_steps; idx = C[b] + Occ(b, idx - 1).  out codes (0..3), out_len.
+struct LfJob { uint64_t row; uint64_t out_off; uint32_t max_steps; uint32_t strand; };
+hipError_t launch_lf_walk(const FmIndexDev& fm, const LfJob* jobs, uint64_t n, uint8_t* out, uint32_t* out_len,
+                          DevCounters* ctr, hipStream_t stream);
 hipError_t launch_bwt_chars(const FmIndexDev& fm, int strand, const uint64_t* idx, uint64_t n, char* out,
                             hipStream_t stream);
 hipError_t launch_find_kmers(const FmIndexDev& fm, const uint8_t* kmer_codes, uint32_t k, uint64_t n,
                              lrsc_biinterval* out, DevCounters* ctr, hipStream_t stream);
 hipError_t launch_kmer_grid(const FmIndexDev& fm, const GridArgs& a, DevCounters* ctr, hipStream_t stream);
+// compact-output grid with quad-cooperative block loads (Block32 indexes only; grid_quad.hip)
+hipError_t launch_kmer_grid_quad(const FmIndexDev& fm, const GridArgs& a, DevCounters* ctr, hipStream_t stream);
 // ASCII -> 2-bit code per byte; *bad set to 1 if a byte is not one of ACGT
 hipError_t launch_encode(const char* ascii, uint8_t* codes, uint64_t n, int* bad, hipStream_t stream);
 hipError_t launch_chunk_table(const uint64_t* read_off, uint32_t n_reads, uint64_t total_bases,

@@ -64,6 +64,46 @@ __global__ __launch_bounds__(256) void bwt_chars_kernel(FmIndexDev fm, int stran
     out[i] = ch;
 }
 
+// One lane per BWT row: BWT[idx] and Occ(BWT[idx], idx - 1) come from the SAME rank block (prefix length idx
+// lives in block idx / kSyms), so an LF step is one 64-byte load.
+template <bool WIDE>
+__global__ __launch_bounds__(256) void lf_walk_kernel(FmIndexDev fm, const LfJob* __restrict__ jobs, uint64_t n,
+                                                      uint8_t* __restrict__ out, uint32_t* __restrict__ out_len, DevCounters* ctr)
+{
+    using L = Lay<WIDE>;
+    using P = typename L::pos_t;
+    __shared__ __attribute__((aligned(16))) uint32_t mtab[MaskTabSize<WIDE>::value];
+    init_mask_table<WIDE>(mtab);
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t n_rank = 0, n_blk = 0;
+    if(i < n) {
+        const LfJob job = jobs[i];
+        const StrandC<P> s0 = strand_consts<P>(fm.strand[0]);
+        const StrandC<P> s1 = strand_consts<P>(fm.strand[1]);
+        const bool second = (job.strand & 1) != 0;
+        uint8_t* dst = out + job.out_off;
+        P idx = (P)job.row;
+        uint32_t len = 0;
+        for(; len < job.max_steps; ++len) {
+            const P b = idx / L::kSyms;
+            const uint32_t off = (uint32_t)(idx - b * L::kSyms);
+            typename L::Regs r;
+            L::load(second ? s1.blocks : s0.blocks, b, r);
+            const uint32_t code = L::symbol(r, off);
+            const bool flagged = L::flagged(r);
+            if(code == 0 && flagged && dollars_in_c(second ? s1 : s0, (uint64_t)idx, (uint64_t)idx + 1) != 0) break;   // '$'
+            dst[len] = (uint8_t)code;
+            uint64_t c = L::count(r, code, mtab + off * L::kRow);
+            if(code == 0 && off != 0 && flagged)
+                c -= dollars_in_c(second ? s1 : s0, (uint64_t)b * L::kSyms, (uint64_t)b * L::kSyms + off);
+            idx = (second ? pred_of(s1, code) : pred_of(s0, code)) + (P)c;
+            n_rank += 1; n_blk += 1;
+        }
+        out_len[i] = len;
+    }
+    flush_counters(ctr, n_rank, n_blk);
+}
+
 template <bool WIDE>
 __global__ __launch_bounds__(256) void find_kmers_kernel(FmIndexDev fm, const uint8_t* __restrict__ codes, uint32_t k,
                                                          uint64_t n, lrsc_biinterval* __restrict__ out, DevCounters* ctr)
@@ -95,7 +135,7 @@ __global__ __launch_bounds__(256) void kmer_grid_kernel(FmIndexDev fm, GridArgs 
     __shared__ __attribute__((aligned(16))) uint32_t mtab[MaskTabSize<WIDE>::value];
     init_mask_table<WIDE>(mtab);
     const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    uint32_t n_rank = 0, n_blk = 0;
+    uint32_t n_rank = 0, n_blk = 0, n_tab = 0;
     if(gid < a.total_bases) {
         // locate the read: coarse table + short forward scan
         uint32_t r = a.chunk_read[gid >> kChunkShift];
@@ -153,7 +193,7 @@ __global__ __launch_bounds__(256) void kmer_grid_kernel(FmIndexDev fm, GridArgs 
                 for(uint32_t j = 0; j < a.n_k && a.ks[j] < tk; ++j) ok = ok && (a.freq_index[j] < 0);
                 if(ok) {
                     st = ts; st.counted = base_k; st.n_rank = 0; st.n_blk = 0;
-                    s0 = tk;
+                    s0 = tk; n_tab = 1;
                     while(slot < a.n_k && a.ks[slot] < tk) ++slot;
                     next_k = slot < a.n_k ? a.ks[slot] : 0xFFFFFFFFu;
                     if(st.size == next_k) { emit(slot); ++slot; next_k = slot < a.n_k ? a.ks[slot] : 0xFFFFFFFFu; }
@@ -174,7 +214,7 @@ __global__ __launch_bounds__(256) void kmer_grid_kernel(FmIndexDev fm, GridArgs 
         if(a.valid_mask) a.valid_mask[gid] = (uint8_t)vmask;
         n_rank = st.n_rank; n_blk = st.n_blk;
     }
-    flush_counters(ctr, n_rank, n_blk);
+    flush_counters(ctr, n_rank, n_blk, n_tab);
 }
 
 // every k-mer's findBiInterval (with early exit) -> table entry; narrow layout only
@@ -235,6 +275,15 @@ hipError_t launch_rank(const FmIndexDev& fm, const lrsc_rank_query* q, uint64_t 
     if(n == 0) return hipSuccess;
     if(fm.wide) hipLaunchKernelGGL(rank_kernel<true>, dim3(blocks_for(n)), dim3(256), 0, stream, fm, q, n, out, ctr);
     else        hipLaunchKernelGGL(rank_kernel<false>, dim3(blocks_for(n)), dim3(256), 0, stream, fm, q, n, out, ctr);
+    return hipGetLastError();
+}
+
+hipError_t launch_lf_walk(const FmIndexDev& fm, const LfJob* jobs, uint64_t n, uint8_t* out, uint32_t* out_len,
+                          DevCounters* ctr, hipStream_t stream)
+{
+    if(n == 0) return hipSuccess;
+    if(fm.wide) hipLaunchKernelGGL(lf_walk_kernel<true>, dim3(blocks_for(n)), dim3(256), 0, stream, fm, jobs, n, out, out_len, ctr);
+    else        hipLaunchKernelGGL(lf_walk_kernel<false>, dim3(blocks_for(n)), dim3(256), 0, stream, fm, jobs, n, out, out_len, ctr);
     return hipGetLastError();
 }
 

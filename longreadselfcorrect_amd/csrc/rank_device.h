@@ -18,7 +18,7 @@ template <> struct Lay<false> {
     static constexpr uint32_t kSyms = Block32::kSyms;
     static constexpr uint32_t kWords = Block32::kWords;
     static constexpr uint32_t kRow = 8;                    // mask-table row stride (u32)
-    struct Regs { uint4 q[4]; };                           // q0 = counts, q1..q3 = lo[6], hi[6]
+    struct Regs { uint4 q[4]; };                           // q0 = counts, q[j] = {lo[2j-2], lo[2j-1], hi[2j-2], hi[2j-1]}
     static __device__ __forceinline__ void load(const void* blocks, uint64_t b, Regs& r)
     {
         const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const Block32*>(blocks) + b);
@@ -34,18 +34,18 @@ template <> struct Lay<false> {
         const uint4 m0 = *reinterpret_cast<const uint4*>(mrow);
         const uint2 m1 = *reinterpret_cast<const uint2*>(mrow + 4);
         uint32_t c = base;
-        c += __builtin_popcount((r.q[1].x ^ L) & (r.q[2].z ^ H) & m0.x);
-        c += __builtin_popcount((r.q[1].y ^ L) & (r.q[2].w ^ H) & m0.y);
-        c += __builtin_popcount((r.q[1].z ^ L) & (r.q[3].x ^ H) & m0.z);
-        c += __builtin_popcount((r.q[1].w ^ L) & (r.q[3].y ^ H) & m0.w);
-        c += __builtin_popcount((r.q[2].x ^ L) & (r.q[3].z ^ H) & m1.x);
-        c += __builtin_popcount((r.q[2].y ^ L) & (r.q[3].w ^ H) & m1.y);
+        c += __builtin_popcount((r.q[1].x ^ L) & (r.q[1].z ^ H) & m0.x);
+        c += __builtin_popcount((r.q[1].y ^ L) & (r.q[1].w ^ H) & m0.y);
+        c += __builtin_popcount((r.q[2].x ^ L) & (r.q[2].z ^ H) & m0.z);
+        c += __builtin_popcount((r.q[2].y ^ L) & (r.q[2].w ^ H) & m0.w);
+        c += __builtin_popcount((r.q[3].x ^ L) & (r.q[3].z ^ H) & m1.x);
+        c += __builtin_popcount((r.q[3].y ^ L) & (r.q[3].w ^ H) & m1.y);
         return c;
     }
     static __device__ __forceinline__ uint32_t symbol(const Regs& r, uint32_t off)
     {
-        const uint32_t lo[6] = {r.q[1].x, r.q[1].y, r.q[1].z, r.q[1].w, r.q[2].x, r.q[2].y};
-        const uint32_t hi[6] = {r.q[2].z, r.q[2].w, r.q[3].x, r.q[3].y, r.q[3].z, r.q[3].w};
+        const uint32_t lo[6] = {r.q[1].x, r.q[1].y, r.q[2].x, r.q[2].y, r.q[3].x, r.q[3].y};
+        const uint32_t hi[6] = {r.q[1].z, r.q[1].w, r.q[2].z, r.q[2].w, r.q[3].z, r.q[3].w};
         uint32_t l = 0, h = 0;
 #pragma unroll
         for(uint32_t i = 0; i < 6; ++i) { l = (off >> 5) == i ? lo[i] : l; h = (off >> 5) == i ? hi[i] : h; }
@@ -211,18 +211,21 @@ __device__ __forceinline__ IvT<P> init_interval(const StrandC<P>& s, uint32_t co
     return iv;
 }
 
-__device__ __forceinline__ void flush_counters(DevCounters* ctr, uint32_t n_rank, uint32_t n_blk)
+__device__ __forceinline__ void flush_counters(DevCounters* ctr, uint32_t n_rank, uint32_t n_blk, uint32_t n_tab = 0)
 {
     if(ctr == nullptr) return;
-    unsigned long long a = n_rank, b = n_blk;
+    unsigned long long a = n_rank, b = n_blk, c = n_tab;
 #pragma unroll
     for(int o = 32; o > 0; o >>= 1) {
         a += __shfl_down(a, o, 64);
         b += __shfl_down(b, o, 64);
+        c += __shfl_down(c, o, 64);
     }
     if((threadIdx.x & 63) == 0) {
-        atomicAdd(&ctr->rank_queries, a);
-        atomicAdd(&ctr->block_loads, b);
+        DevCounters* shard = ctr + (blockIdx.x & (kCtrShards - 1));
+        if(a) atomicAdd(&shard->rank_queries, a);
+        if(b) atomicAdd(&shard->block_loads, b);
+        if(c) atomicAdd(&shard->table_loads, c);
     }
 }
 

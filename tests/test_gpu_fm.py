@@ -375,3 +375,26 @@ def test_repeat_dataset_seeds_walks_and_fasta(api, rep_index, oracle, repeat_ds,
              "exceed_leave_num", "fm_num", "dp_num", "seed_dis", "merge")
     np.testing.assert_array_equal(np.array([[getattr(r, n) for n in names] for r in results], dtype=np.int64), want.counters)
     ctx.close(); want.close(); ob.close(); orb.close()
+
+
+def test_lf_walk_matches_oracle(gpu_ctx, oracle, small_ds):
+    """retrieveStr's LF-walk (LongReadOverlap.cpp:696-749): char by char vs getChar/getPC/getOcc of the oracle,
+    from '$'-adjacent rows, interval rows of real k-mers and random rows, on both strands."""
+    rng = np.random.default_rng(21)
+    for strand, ext in ((0, "bwt"), (1, "rbwt")):
+        ob = oracle.bwt_load(f"{small_ds.prefix}.{ext}")
+        n = ob.num_symbols
+        rows = np.concatenate([np.arange(0, 6), np.arange(small_ds.n_reads - 3, small_ds.n_reads + 3),
+                               rng.integers(0, n, size=40)]).astype(np.uint64)
+        steps = rng.integers(1, 400, size=rows.size).astype(np.uint32)
+        got = gpu_ctx.lf_walk(rows, np.full(rows.size, strand, dtype=np.uint8), steps)
+        for row, ms, g in zip(rows, steps, got):
+            idx, want = int(row), []
+            for _ in range(int(ms)):
+                c = chr(int(ob.chars(np.array([idx], dtype=np.uint64))[0]))
+                if c == "$":
+                    break
+                want.append(c)
+                idx = ob.pc(c) + int(ob.occ(np.frombuffer(c.encode(), dtype=np.uint8), np.array([idx - 1], dtype=np.int64))[0])
+            assert g == "".join(want)
+        ob.close()
