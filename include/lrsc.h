@@ -242,6 +242,12 @@ typedef struct lrsc_read_result {
 int lrsc_correct_reads(lrsc_ctx* ctx, const char* reads, const uint64_t* read_off, uint32_t n_reads,
                        lrsc_read_result* results, uint64_t* piece_off, uint64_t piece_cap, char* out, uint64_t out_cap,
                        uint64_t* n_pieces, uint64_t* out_used);
+/* The same, for a batch that is already resident on the device (lrsc_batch_create): seeds, the chain of
+ * seed-to-seed walks of every read AND the stitching all run on the device (one persistent kernel, one lane
+ * per read); only the corrected strings and the counters come back.  lrsc_correct_reads is this call on a
+ * temporary batch. */
+int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* batch, lrsc_read_result* results, uint64_t* piece_off,
+                       uint64_t piece_cap, char* out, uint64_t out_cap, uint64_t* n_pieces, uint64_t* out_used);
 int lrsc_ctx_get_params(const lrsc_ctx* ctx, lrsc_params* out);
 
 /* ---- DP/MSA fallback building blocks ------------------------------------------------------------------- */

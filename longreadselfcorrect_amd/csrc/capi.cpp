@@ -22,6 +22,7 @@
 #include "fm_layout.h"
 #include "kernels.h"
 #include "extend.h"
+#include "correct_dev.h"
 #include "introsort_emul.h"
 
 using namespace lrsc;
@@ -1067,5 +1068,175 @@ extern "C" int lrsc_extend_walks(lrsc_ctx* ctx, const char* seq, uint64_t seq_le
     }
     *arena_used = used;
     if(used > arena_cap || (!out_arena && used)) return fail(LRSC_ERR_CAPACITY, "output arena too small");
+    return LRSC_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// the whole per-read path on the device
+// ---------------------------------------------------------------------------------------
+// PacBioSelfCorrectionProcess::process for a resident batch: seeds (if not found yet), a plan kernel that
+// bounds every read's walks, the persistent correction kernel (correct_dev.hip) and a gather of the
+// corrected strings.  The host only sizes buffers and copies results.
+extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result* res, uint64_t* piece_off, uint64_t piece_cap,
+                                  char* out, uint64_t out_cap, uint64_t* n_pieces_out, uint64_t* out_used)
+{
+    if(!ctx || !b || b->ctx != ctx || !res || !n_pieces_out || !out_used) return fail(LRSC_ERR_ARG, "null / foreign batch");
+    *n_pieces_out = 0; *out_used = 0;
+    const lrsc_params& p = ctx->params;
+    if(!p.no_dp) return fail(LRSC_ERR_UNSUPPORTED, "the DP/MSA fallback is not part of the product yet: set no_dp");
+    if(p.max_leaves < 1 || p.max_leaves > 32) return fail(LRSC_ERR_UNSUPPORTED, "max_leaves must be 1..32");
+    if(p.idmer_len < 5 || p.idmer_len > 16) return fail(LRSC_ERR_UNSUPPORTED, "idmer_len must be 5..16");
+    if(p.min_kmer_len < p.idmer_len || p.min_kmer_len > 62) return fail(LRSC_ERR_UNSUPPORTED, "min_kmer_len out of range");
+    if(p.next_target < 1) return fail(LRSC_ERR_ARG, "next_target must be >= 1");
+    const uint32_t n = b->n_reads;
+    if(n == 0) return LRSC_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if(!b->seeds_done) {
+        const int st = lrsc_batch_find_seeds(ctx, b);
+        if(st != LRSC_OK) return st;
+    }
+    const bool wide = ctx->fm.wide != 0;
+    const size_t psz = wide ? 8 : 4;
+    const size_t lbytes = leaf_bytes(wide);
+
+    double freqs[101];
+    for(int i = 0; i <= 100; ++i) freqs[i] = 0;
+    for(int i = p.min_kmer_len; i <= 100; i++) freqs[i] = pow(1 - p.error_rate, i) * (size_t)p.pb_coverage;
+
+    // ---- plan: per-read walk bounds from the device-resident seeds ---------------------------------------
+    DevBuf<ReadPlan> d_plan;
+    DevBuf<ReadWork> d_work;
+    DevBuf<ReadOut> d_out;
+    DevBuf<uint32_t> d_order, d_pieces;
+    DevBuf<uint8_t> d_ws, d_codes_out;
+    DevBuf<uint64_t> d_dst_off;
+    DevBuf<char> d_dst;
+    DevBuf<double> d_freqs;
+    HIP_TRY(d_plan.reserve(n));
+    HIP_TRY(d_work.reserve(n));
+    HIP_TRY(d_out.reserve(n));
+    HIP_TRY(d_order.reserve(n));
+    HIP_TRY(d_freqs.reserve(101));
+    HIP_TRY(hipMemcpyAsync(d_freqs.p, freqs, sizeof(freqs), hipMemcpyHostToDevice, ctx->stream));
+
+    CorrectArgs a{};
+    a.codes = b->d_codes; a.read_off = b->d_off; a.seeds = b->d_seeds; a.seed_count = b->d_seed_count;
+    a.n_reads = n; a.min_k = b->min_k;
+    a.plan = d_plan.p; a.out = d_out.p; a.work = d_work.p; a.order = d_order.p;
+    a.seed_size = (uint32_t)p.idmer_len; a.min_overlap = (uint32_t)p.min_kmer_len; a.max_leaves = (uint32_t)p.max_leaves;
+    a.start_kmer_len = p.start_kmer_len; a.next_target = p.next_target; a.split = p.split;
+    a.pb_coverage = (uint64_t)p.pb_coverage; a.pacbio_error_rate = p.error_rate;
+    a.freqs_of_kmer_size = d_freqs.p;
+    a.ctr = ctx->d_ctr;
+    a.reads_per_wave = 16;
+    if(const char* e = std::getenv("LRSC_READS_PER_WAVE")) {
+        const int v = std::atoi(e);
+        if(v >= 1 && v <= 64 && (v & (v - 1)) == 0) a.reads_per_wave = (uint32_t)v;
+    }
+    hipError_t e = launch_correct_plan(a, ctx->stream);
+    if(e != hipSuccess) return hip_fail(e, "correct_plan");
+    std::vector<ReadPlan> plan(n);
+    std::vector<uint32_t> seed_count(n);
+    std::vector<uint64_t> off(n + 1);
+    HIP_TRY(hipMemcpyAsync(plan.data(), d_plan.p, (size_t)n * sizeof(ReadPlan), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(seed_count.data(), b->d_seed_count, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(off.data(), b->d_off, (size_t)(n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+
+    std::vector<ReadWork> work(n);
+    uint64_t ws_total = 0, out_total = 0, piece_total = 0;
+    for(uint32_t r = 0; r < n; ++r) {
+        ReadWork& w = work[r];
+        std::memset(&w, 0, sizeof(w));
+        const uint64_t rlen = off[r + 1] - off[r];
+        const uint32_t ns = seed_count[r];
+        w.out_off = out_total; w.piece_off = piece_total; w.ws_off = ws_total;
+        if(ns < 2) continue;                                          // nothing to correct: the read is discarded
+        // every walk appends at most maxLength + 1 + |target| - initk characters, walks <= seeds, gaps sum to <= |read|
+        const uint64_t cap = rlen + (uint64_t)(1.2 * (double)rlen) + (uint64_t)ns * (2 * kMaxInitK + 16) + 64;
+        if(cap >= (1ull << 32)) return fail(LRSC_ERR_UNSUPPORTED, "read too long");
+        w.out_cap = (uint32_t)cap;
+        w.piece_cap = p.split ? ns : 1;
+        out_total += (cap + 15) & ~15ull;
+        piece_total += w.piece_cap;
+        w.lq_max = plan[r].lq_max;
+        if(w.lq_max >= 65535) return fail(LRSC_ERR_UNSUPPORTED, "walk: query longer than 65534 bases");
+        const double maxLength = (1.2 * ((double)plan[r].gap_max + 10)) + (double)(2 * (uint64_t)kMaxInitK);
+        w.pathw = (uint32_t)(((uint64_t)maxLength + 4 + 15) / 16 + 1);
+        const uint32_t lq = std::max<uint32_t>(w.lq_max, 16);
+        const uint32_t n9 = lq - (uint32_t)p.idmer_len + 1, n5 = lq - 5 + 1;
+        const uint32_t nT = lq;                                       // >= |target| - minOverlap + 1
+        size_t o = 0;
+        w.o_item9f = (uint32_t)o; o += (size_t)n9 * sizeof(SortItem);
+        w.o_item9r = (uint32_t)o; o += (size_t)n9 * sizeof(SortItem);
+        w.o_term = (uint32_t)o;   o = align_up(o + (size_t)nT * 4 * psz, 16);
+        w.o_leaves = (uint32_t)o; o = align_up(o + (size_t)(32 + kMaxChildren) * lbytes, 16);
+        w.o_rings = (uint32_t)o;  o += (size_t)32 * 100 * sizeof(double);
+        w.o_results = (uint32_t)o; o += (size_t)kMaxResults * sizeof(WalkResultRec);
+        w.o_paths = (uint32_t)o;  o += (size_t)(32 + kMaxResults) * w.pathw * 4;
+        w.o_best = (uint32_t)o;   o += (size_t)w.pathw * 4;
+        w.o_next9f = (uint32_t)o; o += (size_t)n9 * 2;
+        w.o_next9r = (uint32_t)o; o += (size_t)n9 * 2;
+        w.o_head9 = (uint32_t)o;  o += 512 * 2;
+        w.o_head5 = (uint32_t)o;  o += 1024 * 2;
+        w.o_next5 = (uint32_t)o;  o += (size_t)n5 * 2;
+        w.o_flags5 = (uint32_t)o; o += n5;
+        w.o_query = (uint32_t)o;  o += lq;
+        o = align_up(o, 64);
+        if(o >= (1ull << 32)) return fail(LRSC_ERR_UNSUPPORTED, "read workspace too large");
+        ws_total += o;
+    }
+    // launch order: long reads first, similar lengths share a wavefront
+    std::vector<uint32_t> order(n);
+    for(uint32_t i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return off[x + 1] - off[x] > off[y + 1] - off[y]; });
+
+    HIP_TRY(d_ws.reserve(std::max<uint64_t>(ws_total, 64)));
+    HIP_TRY(d_codes_out.reserve(std::max<uint64_t>(out_total, 64)));
+    HIP_TRY(d_pieces.reserve(std::max<uint64_t>(piece_total, 1)));
+    HIP_TRY(hipMemcpyAsync(d_work.p, work.data(), (size_t)n * sizeof(ReadWork), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_order.p, order.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    a.workspace = d_ws.p; a.out_codes = d_codes_out.p; a.piece_start = d_pieces.p;
+
+    int st = timed_launch(ctx, LRSC_K_EXTEND, [&]() { return launch_correct_reads(ctx->fm, a, ctx->stream); });
+    if(st != LRSC_OK) return st;
+
+    // ---- results ---------------------------------------------------------------------------------------------
+    std::vector<ReadOut> ro(n);
+    HIP_TRY(hipMemcpy(ro.data(), d_out.p, (size_t)n * sizeof(ReadOut), hipMemcpyDeviceToHost));
+    std::vector<uint32_t> pieces(std::max<uint64_t>(piece_total, 1));
+    if(piece_total) HIP_TRY(hipMemcpy(pieces.data(), d_pieces.p, (size_t)piece_total * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    std::vector<uint64_t> dst_off(n + 1, 0);
+    uint64_t n_pieces = 0;
+    for(uint32_t r = 0; r < n; ++r) {
+        const ReadOut& o = ro[r];
+        if(o.error == LRSC_WALK_ERR_GEOMETRY) return fail(LRSC_ERR_ARG, "correct: a walk's geometry is out of range (seed shorter than the extension k-mer, overlapping seeds, or init k-mer > 59)");
+        if(o.error == LRSC_WALK_ERR_CODE) return fail(LRSC_ERR_UNSUPPORTED, "correct: FM-extension returned -4");
+        if(o.error != 0) return fail(LRSC_ERR_CAPACITY, "correct: internal frontier/result/output capacity exceeded");
+        lrsc_read_result& R = res[r];
+        R.merge = (int32_t)o.merge; R.n_pieces = o.n_pieces; R.piece_first = n_pieces;
+        R.total_reads_len = o.c[0]; R.corrected_len = o.c[1]; R.total_seed_num = o.c[2]; R.total_walk_num = o.c[3];
+        R.high_error_num = o.c[4]; R.exceed_depth_num = o.c[5]; R.exceed_leave_num = o.c[6]; R.fm_num = o.c[7];
+        R.dp_num = o.c[8]; R.seed_dis = o.c[9];
+        dst_off[r + 1] = dst_off[r] + o.out_len;
+        for(uint32_t j = 0; j < o.n_pieces; ++j) {
+            if(piece_off && n_pieces < piece_cap) piece_off[n_pieces] = dst_off[r] + pieces[work[r].piece_off + j];
+            ++n_pieces;
+        }
+    }
+    const uint64_t used = dst_off[n];
+    if(piece_off && n_pieces < piece_cap) piece_off[n_pieces] = used;
+    *n_pieces_out = n_pieces;
+    *out_used = used;
+    if(!out || !piece_off || used > out_cap || n_pieces + 1 > piece_cap) return fail(LRSC_ERR_CAPACITY, "output buffers too small");
+    if(used) {
+        HIP_TRY(d_dst_off.reserve(n + 1));
+        HIP_TRY(d_dst.reserve(used));
+        HIP_TRY(hipMemcpyAsync(d_dst_off.p, dst_off.data(), (size_t)(n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+        e = launch_correct_gather(a, d_dst_off.p, d_dst.p, ctx->stream);
+        if(e != hipSuccess) return hip_fail(e, "correct_gather");
+        HIP_TRY(hipMemcpyAsync(out, d_dst.p, used, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
     return LRSC_OK;
 }

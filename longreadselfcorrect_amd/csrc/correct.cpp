@@ -8,6 +8,7 @@
 // stitches the results between rounds.  Pure host C++ over the C ABI; no device code here.
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -83,6 +84,18 @@ extern "C" int lrsc_correct_reads(lrsc_ctx* ctx, const char* reads, const uint64
     *n_pieces_out = 0; *out_used = 0;
     if(n_reads == 0) return LRSC_OK;
     if(!params->no_dp) return LRSC_ERR_UNSUPPORTED;       // the DP/MSA fallback (correctByMSAlignment) is not in the product yet
+
+    // Default: everything on the device (lrsc_batch_correct).  LRSC_CORRECT_MODE=rounds keeps the host-stitched
+    // rounds below, which the tests run as an independent cross-check of the persistent kernel.
+    const char* mode = std::getenv("LRSC_CORRECT_MODE");
+    if(!(mode && std::strcmp(mode, "rounds") == 0)) {
+        lrsc_batch* db = nullptr;
+        int dst = lrsc_batch_create(ctx, reads, read_off, n_reads, &db);
+        if(dst != LRSC_OK) return dst;
+        dst = lrsc_batch_correct(ctx, db, res, piece_off, piece_cap, out, out_cap, n_pieces_out, out_used);
+        lrsc_batch_destroy(db);
+        return dst;
+    }
 
     // ---- Part 1: seeds (LongReadProbe::searchSeedsWithHybridKmers) on the device ----------------------------------
     lrsc_batch* batch = nullptr;

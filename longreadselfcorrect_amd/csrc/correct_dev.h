@@ -1,0 +1,66 @@
+// correct_dev.h -- host/device interface of the persistent per-read correction kernel (correct_dev.hip).
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include "extend.h"
+
+namespace lrsc {
+
+enum { LRSC_WALK_ERR_GEOMETRY = -103, LRSC_WALK_ERR_OUTPUT = -104, LRSC_WALK_ERR_CODE = -105 };
+
+constexpr uint32_t kMaxInitK = 59;       // initk + 2 = maxOverlap must stay below the 64-character suffix window
+
+// per-read bounds found by correct_plan_kernel: the host sizes the read's workspace from them
+struct ReadPlan {
+    uint32_t gap_max;        // longest raw segment any walk of this read can be asked to bridge
+    uint32_t lq_max;         // longest m_query = kMaxInitK + gap + target seed
+};
+
+// per-read workspace layout (bytes from CorrectArgs::workspace + ws_off) and output slots
+struct ReadWork {
+    uint64_t ws_off;
+    uint64_t out_off;        // into out_codes
+    uint64_t piece_off;      // into piece_start
+    uint32_t lq_max, pathw, out_cap, piece_cap;
+    uint32_t o_item9f, o_item9r, o_next9f, o_next9r, o_head9, o_head5, o_next5, o_flags5, o_term, o_leaves, o_rings,
+        o_paths, o_results, o_query, o_best;
+};
+
+struct ReadOut {             // PacBioSelfCorrectionResult (PacBioSelfCorrectionProcess.h:58-94) without the strings
+    int64_t c[10];           // totalReadsLen, correctedLen, totalSeedNum, totalWalkNum, highErrorNum, exceedDepthNum,
+                             // exceedLeaveNum, FMNum, DPNum, seedDis
+    uint64_t steps;
+    uint32_t n_pieces, out_len, merge;
+    int32_t error;
+};
+
+struct CorrectArgs {
+    const uint8_t* codes;            // batch reads, 2-bit codes one per byte
+    const uint64_t* read_off;
+    const int32_t* seeds;            // kSeedInts per seed, slab of read r at seed_slab(read_off[r], r, min_k)
+    const uint32_t* seed_count;
+    const uint32_t* order;           // launch order (similar lengths share a wavefront)
+    const ReadWork* work;
+    uint32_t n_reads, min_k;
+    uint32_t reads_per_wave;         // 1..64, power of two: 64 / reads_per_wave lanes apart
+    uint8_t* workspace;
+    uint8_t* out_codes;
+    uint32_t* piece_start;
+    ReadOut* out;
+    ReadPlan* plan;                  // plan kernel only
+    // FMextendParameters / PacBioSelfCorrectionParameters
+    uint32_t seed_size, min_overlap, max_leaves;
+    int32_t start_kmer_len, next_target, split;
+    uint64_t pb_coverage;
+    double pacbio_error_rate;
+    const double* freqs_of_kmer_size;
+    DevCounters* ctr;
+};
+
+hipError_t launch_correct_plan(const CorrectArgs& a, hipStream_t stream);
+hipError_t launch_correct_reads(const FmIndexDev& fm, const CorrectArgs& a, hipStream_t stream);
+// out_codes -> ASCII, packed at dst + dst_off[r]
+hipError_t launch_correct_gather(const CorrectArgs& a, const uint64_t* dst_off, char* dst, hipStream_t stream);
+
+} // namespace lrsc

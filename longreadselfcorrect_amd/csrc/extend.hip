@@ -22,14 +22,11 @@
 // All double arithmetic is evaluated in the reference's order; the file is built with -ffp-contract=off.
 #include <hip/hip_runtime.h>
 
-#include "extend.h"
-#include "introsort_emul.h"
-#include "rank_device.h"
+#include "walk_device.h"
 
 namespace lrsc {
 
 constexpr uint32_t kWalksPerWave = 64;
-constexpr uint64_t kNoKey = ~0ull;
 
 // ---------------------------------------------------------------------------------------
 // 1. prepare
@@ -43,644 +40,19 @@ __global__ __launch_bounds__(256) void walk_prepare_kernel(FmIndexDev fm, Extend
     const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     uint32_t cnt_rank = 0, cnt_blk = 0;
     if(gid < a.total_q) {
-    uint32_t w = a.chunk_walk[gid >> kChunkShift];
-    while(a.q_off[w + 1] <= gid) ++w;
-    const WalkWork ww = a.work[w];
-    const uint32_t i = (uint32_t)(gid - a.q_off[w]);          // offset inside m_query
-    const uint32_t Lq = ww.lq;
-    const uint8_t* q = a.codes + ww.codes_off;
-    uint8_t* ws = a.workspace + ww.ws_off;
-    SortItem* it9f = reinterpret_cast<SortItem*>(ws + ww.o_item9f);
-    SortItem* it9r = reinterpret_cast<SortItem*>(ws + ww.o_item9r);
-    uint8_t* flags5 = ws + ww.o_flags5;
-    P* term = reinterpret_cast<P*>(ws + ww.o_term);
-
-    const StrandC<P> sf = strand_consts<P>(fm.strand[LRSC_RBWT]);
-    const StrandC<P> sr = strand_consts<P>(fm.strand[LRSC_BWT]);
-    const uint32_t seedk = a.seed_size, mink = a.min_overlap;
-    const uint32_t trg0 = ww.initk + ww.path_len;            // first offset of the target seed
-    const bool want_term = i >= trg0 && i + mink <= Lq;
-    uint32_t kmax = 0;
-    if(i + 5 <= Lq) kmax = 5;
-    if(i + seedk <= Lq) kmax = seedk;
-    if(want_term) kmax = mink > kmax ? mink : kmax;
-
-    WalkState<P> st = walk_init<P>();
-    uint32_t n_rank_acc = 0, n_blk_acc = 0;
-    for(uint32_t s = 0; s < kmax;) {
-        // jump to the next emission size through a k-mer table when one of exactly that size exists
-        const uint32_t next_emit = s < 5 ? 5u : s < seedk ? seedk : mink;
-        if(!WIDE && next_emit <= kmax) {
-            WalkState<P> ts = walk_init<P>();
-            const uint32_t tk = table_start<WIDE>(fm, [&](uint32_t t) { return (uint32_t)q[i + t]; }, next_emit, ts);
-            if(tk == next_emit) { n_rank_acc += st.n_rank; n_blk_acc += st.n_blk; st = ts; st.n_rank = 0; st.n_blk = 0; s = tk; }
-            else { st = walk_step<WIDE>(sf, sr, q[i + s], 1u << 30, st, mtab); ++s; }
-        } else { st = walk_step<WIDE>(sf, sr, q[i + s], 1u << 30, st, mtab); ++s; }     // findInterval semantics, early exit per strand
-        if(st.size == 5) flags5[i] = (uint8_t)((st.fwd.lo <= st.fwd.hi ? 1 : 0) | (st.rvc.lo <= st.rvc.hi ? 2 : 0));
-        if(st.size == seedk) {
-            it9f[i].key = st.fwd.lo <= st.fwd.hi ? (uint64_t)st.fwd.lo : kNoKey; it9f[i].val = i; it9f[i].pad = 0;
-            it9r[i].key = st.rvc.lo <= st.rvc.hi ? (uint64_t)st.rvc.lo : kNoKey; it9r[i].val = i; it9r[i].pad = 0;
-        }
-        if(st.size == mink && want_term) {
-            P* t = term + (uint64_t)(i - trg0) * 4;
-            t[0] = st.fwd.lo; t[1] = st.fwd.hi; t[2] = st.rvc.lo; t[3] = st.rvc.hi;
-        }
-    }
-    cnt_rank = st.n_rank + n_rank_acc; cnt_blk = st.n_blk + n_blk_acc;
+        uint32_t w = a.chunk_walk[gid >> kChunkShift];
+        while(a.q_off[w + 1] <= gid) ++w;
+        const WalkWork ww = a.work[w];
+        const uint32_t i = (uint32_t)(gid - a.q_off[w]);          // offset inside m_query
+        uint8_t* ws = a.workspace + ww.ws_off;
+        const StrandC<P> sf = strand_consts<P>(fm.strand[LRSC_RBWT]);
+        const StrandC<P> sr = strand_consts<P>(fm.strand[LRSC_BWT]);
+        prepare_offset<WIDE>(fm, sf, sr, mtab, a.codes + ww.codes_off, i, ww.lq, ww.initk + ww.path_len, a.seed_size, a.min_overlap,
+                             reinterpret_cast<SortItem*>(ws + ww.o_item9f), reinterpret_cast<SortItem*>(ws + ww.o_item9r),
+                             ws + ww.o_flags5, reinterpret_cast<P*>(ws + ww.o_term), cnt_rank, cnt_blk);
     }
     flush_counters(a.ctr, cnt_rank, cnt_blk);
 }
-
-// ---------------------------------------------------------------------------------------
-// 2. the walk
-// ---------------------------------------------------------------------------------------
-template <class P>
-struct Leaf {                         // SAIOverlapNode3 + leafInfo, flattened
-    P flo, fhi, rlo, rhi;             // fwdInterval (rbwt), rvcInterval (bwt)
-    P tflo, tfhi, trlo, trhi;         // SelectFreqsOfrange's per-leaf scratch intervals (maxKmerArray)
-    uint64_t suf_lo, suf_hi;          // last 64 characters of the path, 2 bits each, newest in the low bits
-    uint64_t lastSeedIdx, lastOverlapLen, totalSeeds, currOverlapLen, numOfErrors, queryOverlapLen;
-    double numRedeemSeed, localErr, globalErr;
-    uint32_t hist_size;               // GlobalErrorRateRecord.size()
-    int32_t lastSeedIdxOffset;
-    int32_t res_first, res_second;    // resultindex
-    int32_t kmerFrequency;            // leafInfo::kmerFrequency
-    int32_t tmpFreq;                  // SelectFreqsOfrange: FMidx::kmerFrequency
-    uint32_t tailLetter, tailLetterCount;
-    uint32_t path_len;
-    uint16_t ring, path;              // slot ids (materialised leaves only)
-    uint16_t parent;                  // children: index of the parent in cur[]
-    uint8_t ext, alive;               // children: extension code; survival flag
-};
-
-template <class P> __device__ __forceinline__ int64_t isize(P lo, P hi) { return (int64_t)hi - (int64_t)lo + 1; }
-
-// character `t` (0 = oldest) of the suffix of length l of a leaf's path
-template <class P> __device__ __forceinline__ uint32_t suf_char(const Leaf<P>& lf, uint32_t l, uint32_t t)
-{
-    const uint32_t back = l - 1 - t;                     // distance from the newest character
-    return back < 32 ? (uint32_t)(lf.suf_lo >> (2 * back)) & 3u : (uint32_t)(lf.suf_hi >> (2 * (back - 32))) & 3u;
-}
-template <class P> __device__ __forceinline__ void suf_push(Leaf<P>& lf, uint32_t c)
-{
-    lf.suf_hi = (lf.suf_hi << 2) | (lf.suf_lo >> 62);
-    lf.suf_lo = (lf.suf_lo << 2) | c;
-}
-
-__device__ __forceinline__ uint32_t path_get(const uint32_t* p, uint32_t i) { return (p[i >> 4] >> (2 * (i & 15))) & 3u; }
-__device__ __forceinline__ void path_set(uint32_t* p, uint32_t i, uint32_t c)
-{
-    const uint32_t sh = 2 * (i & 15);
-    p[i >> 4] = (p[i >> 4] & ~(3u << sh)) | (c << sh);
-}
-
-template <bool WIDE>
-struct Walk {
-    using P = typename Lay<WIDE>::pos_t;
-    // index
-    StrandC<P> sF, sR;
-    const FmIndexDev* fm;
-    const uint32_t* mtab;
-    // inputs
-    const uint8_t* q;                 // m_query codes
-    uint32_t Lq, initk, path_len, trg_len;
-    int32_t dis;
-    // parameters
-    uint32_t seedSize, minOverlap, maxOverlap, maxLeaves;
-    uint64_t min_SA_threshold;
-    uint64_t PBcoverage;
-    double PacBioErrorRate, errorRate;
-    uint64_t localK;                  // m_localSimilarlykmerSize (100)
-    const double* freqsOfKmerSize;    // [101]
-    // derived
-    uint64_t maxIndelSize, maxLength, minLength, currentLength, currentKmerSize;
-    // workspace
-    SortItem *it9f, *it9r;
-    uint32_t n9f, n9r;
-    uint16_t *next9f, *next9r, *head9f, *head9r;      // chains in sorted order, 256 hash buckets
-    uint16_t *next5, *head5;                          // 5-mer chains by code (1024 heads), flags5 tells strand validity
-    const uint8_t* flags5;
-    const P* term;
-    uint32_t n_term;
-    Leaf<P>* cur;  uint32_t n_cur;
-    Leaf<P>* nxt;  uint32_t n_nxt;
-    double* rings;                    // [32][100]
-    uint32_t* paths;  uint32_t pathw; // [32][pathw]
-    uint32_t* rpaths;                 // [kMaxResults][pathw]
-    WalkResultRec* results; uint32_t n_results;
-    uint8_t ring_free[32], path_free[32]; uint32_t n_ring_free, n_path_free;
-    uint32_t n_rank, n_blk;
-    uint64_t steps;
-    int error;
-
-    __device__ __forceinline__ IvT<P> upd(const StrandC<P>& s, uint32_t c, IvT<P> iv) { n_rank += 2; return update_interval<WIDE>(s, c, iv, mtab, n_blk); }
-
-    // findInterval of the leaf's suffix of length l on both strands (initialRootNode / refineSAInterval):
-    // fwd = reverse(kmer) in the rbwt, rvc = revcomp(kmer) in the bwt; both consume kmer[0], kmer[1], ... in order
-    __device__ void find_suffix(Leaf<P>& lf, uint32_t l)
-    {
-        WalkState<P> st = walk_init<P>();
-        const uint32_t t0 = table_start<WIDE>(*fm, [&](uint32_t t) { return suf_char(lf, l, t); }, l, st);
-        for(uint32_t t = t0; t < l; ++t) {
-            if(st.fwd_broken && st.rvc_broken) break;
-            st = walk_step<WIDE>(sF, sR, suf_char(lf, l, t), 1u << 30, st, mtab);
-        }
-        n_rank += st.n_rank; n_blk += st.n_blk;
-        lf.flo = st.fwd.lo; lf.fhi = st.fwd.hi; lf.rlo = st.rvc.lo; lf.rhi = st.rvc.hi;
-    }
-
-    __device__ void refineSAInterval(Leaf<P>* leaves, uint32_t n, uint64_t newKmerSize)   // .cpp:355-369
-    {
-        for(uint32_t i = 0; i < n; ++i) find_suffix(leaves[i], (uint32_t)newKmerSize);
-        currentKmerSize = newKmerSize;
-    }
-
-    // ---- SelectFreqsOfrange (.cpp:281-331) ---------------------------------------------------------
-    __device__ uint64_t SelectFreqsOfrange(uint64_t LowerBound, uint64_t UpperBound, Leaf<P>* leaves, uint32_t n)
-    {
-        int tempmaxfmfreqs = 0;
-        const uint32_t U = (uint32_t)UpperBound, Lw = (uint32_t)LowerBound;
-        for(uint32_t j = 0; j < n; ++j) {
-            Leaf<P>& lf = leaves[j];
-            // startkmer = last Lw chars of the suffix of length U; Fwd = findInterval(BWT, startkmer) walks it from
-            // its last character backwards; Rvc = findInterval(RBWT, complement(startkmer)) likewise
-            IvT<P> f = init_interval<P>(sR, suf_char(lf, U, U - 1));
-            IvT<P> r = init_interval<P>(sF, 3u - suf_char(lf, U, U - 1));
-            n_rank += 2;
-            bool fb = false, rb = false;
-            for(uint32_t t = 1; t < Lw; ++t) {
-                const uint32_t c = suf_char(lf, U, U - 1 - t);
-                if(!fb) { f = upd(sR, c, f); fb = f.lo > f.hi; }
-                if(!rb) { r = upd(sF, 3u - c, r); rb = r.lo > r.hi; }
-                if(fb && rb) break;
-            }
-            lf.tflo = f.lo; lf.tfhi = f.hi; lf.trlo = r.lo; lf.trhi = r.hi;
-            lf.tmpFreq = (int)(isize(f.lo, f.hi) + isize(r.lo, r.hi));
-            if(lf.tmpFreq > tempmaxfmfreqs) tempmaxfmfreqs = lf.tmpFreq;
-        }
-        if(tempmaxfmfreqs - (int)freqsOfKmerSize[LowerBound] < 5) return LowerBound;
-
-        for(uint64_t i = 1; i <= UpperBound - LowerBound; i++) {
-            tempmaxfmfreqs = 0;
-            for(uint32_t j = 0; j < n; ++j) {
-                Leaf<P>& lf = leaves[j];
-                const uint32_t b = suf_char(lf, U, (uint32_t)(UpperBound - LowerBound - i));
-                IvT<P> f{lf.tflo, lf.tfhi}, r{lf.trlo, lf.trhi};
-                f = upd(sR, b, f);                           // no validity check here (.cpp:317-318)
-                r = upd(sF, 3u - b, r);
-                lf.tflo = f.lo; lf.tfhi = f.hi; lf.trlo = r.lo; lf.trhi = r.hi;
-                lf.tmpFreq = (int)(isize(f.lo, f.hi) + isize(r.lo, r.hi));
-                if(lf.tmpFreq > tempmaxfmfreqs) tempmaxfmfreqs = lf.tmpFreq;
-            }
-            if(tempmaxfmfreqs - (int)freqsOfKmerSize[LowerBound + i] < 5) return LowerBound + i;
-        }
-        return UpperBound;
-    }
-
-    __device__ bool isInsufficientFreqs(const Leaf<P>* leaves, uint32_t n)     // .cpp:334-352
-    {
-        uint64_t highfreqscount = 0;
-        for(uint32_t i = 0; i < n; ++i) {
-            const int highfreqThreshold = PBcoverage > 60 ? (int)((uint64_t)(PBcoverage / 60) * 3) : 3;
-            if(leaves[i].kmerFrequency > highfreqThreshold) highfreqscount++;
-        }
-        if(highfreqscount == 0) return true;
-        else if(highfreqscount <= 2 && n >= 5) return true;
-        else if(highfreqscount <= 1 && n >= 3) return true;
-        return false;
-    }
-
-    // ---- ismatchedbykmer (.cpp:787-821): any 5-mer hit of the extended path within the indel window --------
-    __device__ bool ismatchedbykmer(uint32_t code5, bool fvalid, bool rvalid)
-    {
-        const uint64_t startSeedIdx = (uint64_t)(((int)currentLength - (int)maxIndelSize) > 0 ? ((int)currentLength - (int)maxIndelSize) : 0);
-        const uint64_t largeSeedIdx = currentLength + maxIndelSize;
-        for(uint32_t j = head5[code5]; j != 0xFFFFu; j = next5[j]) {
-            if(j >= startSeedIdx && j <= largeSeedIdx) {
-                const uint32_t fl = flags5[j];
-                if((fvalid && (fl & 1)) || (rvalid && (fl & 2))) return true;
-            }
-        }
-        return false;
-    }
-
-    // ---- getFMIndexExtensions (.cpp:667-784): returns a bit mask of accepted bases, fills ext[] -------------
-    struct Ext { IvT<P> f, r; int freq; };
-    __device__ uint32_t getFMIndexExtensions(const Leaf<P>& lf, Ext ext[4], uint64_t& totalcount_out)
-    {
-        const uint64_t IntervalSizeCutoff = min_SA_threshold;
-        uint64_t totalcount = 0;
-        int maxfreqsofleave = 0;
-        const bool fv = lf.flo <= lf.fhi, rv = lf.rlo <= lf.rhi;
-#pragma unroll
-        for(uint32_t b = 0; b < 4; ++b) {
-            IvT<P> fp{lf.flo, lf.fhi}, rp{lf.rlo, lf.rhi};
-            if(fv) fp = upd(sF, b, fp);
-            if(rv) rp = upd(sR, 3u - b, rp);
-            ext[b].f = fp; ext[b].r = rp;
-            ext[b].freq = (int)(isize(fp.lo, fp.hi) + isize(rp.lo, rp.hi));
-            totalcount += (uint64_t)(int64_t)ext[b].freq;
-            if(ext[b].freq > maxfreqsofleave) maxfreqsofleave = ext[b].freq;
-        }
-        totalcount_out = totalcount;
-        uint32_t mask = 0;
-        const bool isHomopolymer = lf.tailLetterCount >= 3;
-        for(uint32_t b = 0; b < 4; ++b) {
-            const uint64_t kmerFreq = (uint64_t)(int64_t)ext[b].freq;
-            const double kmerRatioNotPass = 2;
-            double kmerRatioCutoff = 0;
-            const double kmerRatio = (double)kmerFreq / (double)maxfreqsofleave;
-            const bool efv = ext[b].f.lo <= ext[b].f.hi, erv = ext[b].r.lo <= ext[b].r.hi;
-            const uint32_t code5 = (uint32_t)(((lf.suf_lo << 2) | b) & 0x3FFu);
-            const bool isMatchedBy5mer = ismatchedbykmer(code5, efv, erv);
-            const bool isFreqPass = kmerFreq >= IntervalSizeCutoff;
-            const bool isLowCoverage = totalcount >= IntervalSizeCutoff + 2;
-            const bool isRepeat = maxfreqsofleave > 100;
-            const bool isHighlyRepeat = maxfreqsofleave > 150;
-            const bool isLowlyRepeat = maxfreqsofleave > 50;
-            if(isMatchedBy5mer && isHighlyRepeat) kmerRatioCutoff = 0.125;
-            else if(isMatchedBy5mer && isLowlyRepeat) kmerRatioCutoff = 0.2;
-            else if(isFreqPass) kmerRatioCutoff = 0.25;
-            else if(isLowCoverage) kmerRatioCutoff = 0.6;
-            else kmerRatioCutoff = kmerRatioNotPass;
-            if(isHomopolymer && isRepeat) kmerRatioCutoff = kmerRatioCutoff > 0.3 ? kmerRatioCutoff : 0.3;
-            else if(isHomopolymer) kmerRatioCutoff = kmerRatioCutoff > 0.6 ? kmerRatioCutoff : 0.6;
-            if(kmerRatio >= kmerRatioCutoff) mask |= 1u << b;
-        }
-        return mask;
-    }
-
-    __device__ void free_leaf_slots(const Leaf<P>& lf)
-    {
-        ring_free[n_ring_free++] = (uint8_t)lf.ring;
-        path_free[n_path_free++] = (uint8_t)lf.path;
-    }
-
-    // ---- attempToExtend (.cpp:373-465) + updateLeaves (:468-488) -------------------------------------------
-    __device__ void attempToExtend()
-    {
-        double minimumErrorRate = 1;
-        for(uint32_t i = 0; i < n_cur; ++i)
-            if(cur[i].localErr < minimumErrorRate) minimumErrorRate = cur[i].localErr;
-        // trim leaves whose error rate relative to the best one is high
-        uint32_t w = 0;
-        for(uint32_t i = 0; i < n_cur; ++i) {
-            const double errorRateDiff = cur[i].localErr - minimumErrorRate;
-            if((errorRateDiff > 0.05 && currentLength > localK / 2) || (errorRateDiff > 0.1 && currentLength > 15)) {
-                free_leaf_slots(cur[i]);
-                continue;
-            }
-            if(w != i) cur[w] = cur[i];
-            ++w;
-        }
-        n_cur = w;
-
-        for(uint32_t i = 0; i < n_cur; ++i) {
-            Ext ext[4];
-            uint32_t mask = 0;
-            int count = 0;
-            while(count < 2) {
-                if(count == 1 && !(cur[i].localErr == minimumErrorRate && n_cur > 1)) break;
-                uint64_t tc;
-                mask = getFMIndexExtensions(cur[i], ext, tc);
-                if(mask != 0) break;
-                min_SA_threshold--;
-                count++;
-            }
-            min_SA_threshold += (uint64_t)count;
-            if(mask == 0) continue;
-            // updateLeaves: children in base order; leafInfo(child) fields (LongReadCorrectByOverlap.h:172-203)
-            for(uint32_t b = 0; b < 4; ++b) {
-                if(!(mask & (1u << b))) continue;
-                if(n_nxt >= kMaxChildren) { error = LRSC_WALK_ERR_CHILDREN; return; }
-                Leaf<P>& ch = nxt[n_nxt++];
-                ch = cur[i];                               // createChild copies the node state (SAINode.cpp:166-189)
-                ch.flo = ext[b].f.lo; ch.fhi = ext[b].f.hi; ch.rlo = ext[b].r.lo; ch.rhi = ext[b].r.hi;
-                ch.kmerFrequency = ext[b].freq;
-                ch.currOverlapLen++;
-                ch.queryOverlapLen++;
-                if(cur[i].tailLetter == b) ch.tailLetterCount = cur[i].tailLetterCount + 1;
-                else { ch.tailLetter = b; ch.tailLetterCount = 1; }
-                suf_push(ch, b);
-                ch.parent = (uint16_t)i;
-                ch.ext = (uint8_t)b;
-                ch.alive = 1;
-            }
-        }
-    }
-
-    // ---- extendLeaves (.cpp:239-278) ------------------------------------------------------------------------
-    __device__ void extendLeaves()
-    {
-        n_nxt = 0;
-        if(currentKmerSize > maxOverlap) refineSAInterval(cur, n_cur, maxOverlap);
-        attempToExtend();
-        if(error) return;
-        if(n_nxt == 0) {                                    // level 1: reduce the k-mer size
-            const uint64_t LowerBound = (currentKmerSize - 2) > minOverlap ? (currentKmerSize - 2) : minOverlap;
-            const uint64_t ReduceSize = SelectFreqsOfrange(LowerBound, currentKmerSize, cur, n_cur);
-            refineSAInterval(cur, n_cur, ReduceSize);
-            attempToExtend();
-            if(error) return;
-            if(n_nxt == 0) {                                // level 2: reduce the threshold
-                min_SA_threshold--;
-                attempToExtend();
-                min_SA_threshold++;
-                if(error) return;
-            }
-        }
-        if(n_nxt != 0) {
-            currentLength++;
-            currentKmerSize++;
-            if(isInsufficientFreqs(nxt, n_nxt)) {           // frequencies are low: relax the k-mer size
-                const uint64_t LowerBound = (currentKmerSize - 2) > minOverlap ? (currentKmerSize - 2) : minOverlap;
-                const uint64_t ReduceSize = SelectFreqsOfrange(LowerBound, currentKmerSize, nxt, n_nxt);
-                refineSAInterval(nxt, n_nxt, ReduceSize);
-            }
-        }
-    }
-
-    // ---- isSupportedByNewSeed (.cpp:566-635) ------------------------------------------------------------------
-    __device__ bool isSupportedByNewSeed(Leaf<P>& nd, uint64_t smallSeedIdx, uint64_t largeSeedIdx)
-    {
-        const uint64_t seedIdxOffset = nd.lastOverlapLen < currentLength - seedSize ? (uint64_t)seedSize : currentLength - nd.lastOverlapLen;
-        const uint64_t cand = nd.lastSeedIdx + seedIdxOffset;
-        const uint64_t startSeedIdx = smallSeedIdx > cand ? smallSeedIdx : cand;
-        bool isNewSeedFound = false;
-        const bool fv = nd.flo <= nd.fhi, rv = nd.rlo <= nd.rhi;
-        const uint32_t mask9 = seedSize >= 16 ? 0xFFFFFFFFu : ((1u << (2 * seedSize)) - 1u);
-        const uint32_t code9 = (uint32_t)nd.suf_lo & mask9;
-        const uint32_t hb = (code9 ^ (code9 >> 9)) & 255u;
-        // fwd / rvc hit lists in post-sort order: entries of this k-mer chained in the bucket
-        uint32_t jf = fv ? head9f[hb] : 0xFFFFu;
-        uint32_t jr = rv ? head9r[hb] : 0xFFFFu;
-        auto advance = [&](uint32_t j, const SortItem* it, const uint16_t* nx) -> uint32_t {
-            while(j != 0xFFFFu && kmer_code(it[j].val) != code9) j = nx[j];
-            return j;
-        };
-        jf = advance(jf, it9f, next9f);
-        jr = advance(jr, it9r, next9r);
-        int minIdxDiff = 10000;
-        const uint64_t currSeedIdx = currentLength - seedSize;
-        while(jf != 0xFFFFu || jr != 0xFFFFu) {
-            const uint64_t vf = jf != 0xFFFFu ? it9f[jf].val : 0, vr = jr != 0xFFFFu ? it9r[jr].val : 0;
-            if(fv && jf != 0xFFFFu && vf >= startSeedIdx && vf <= largeSeedIdx) {
-                const int d = abs((int)vf - (int)currSeedIdx);
-                if(d < minIdxDiff) { nd.lastSeedIdx = vf; nd.queryOverlapLen = vf + seedSize; minIdxDiff = d; }
-                nd.lastOverlapLen = currentLength;
-                nd.currOverlapLen = currentLength;
-                isNewSeedFound = true;
-            } else if(rv && jr != 0xFFFFu && vr >= startSeedIdx && vr <= largeSeedIdx) {
-                const int d = abs((int)currSeedIdx - (int)vr);
-                if(d < minIdxDiff) { nd.lastSeedIdx = vr; nd.queryOverlapLen = vr + seedSize; minIdxDiff = d; }
-                nd.lastOverlapLen = currentLength;
-                nd.currOverlapLen = currentLength;
-                isNewSeedFound = true;
-            }
-            if(jf != 0xFFFFu) jf = advance(next9f[jf], it9f, next9f);
-            if(jr != 0xFFFFu) jr = advance(next9r[jr], it9r, next9r);
-        }
-        if(isNewSeedFound) nd.totalSeeds++;
-        return isNewSeedFound;
-    }
-
-    // seedSize-mer code of m_query at offset i (first character in the high bits)
-    __device__ __forceinline__ uint32_t kmer_code(uint32_t i) const
-    {
-        uint32_t c = 0;
-        for(uint32_t t = 0; t < seedSize; ++t) c = (c << 2) | q[i + t];
-        return c;
-    }
-
-    // ---- computeErrorRate (.cpp:638-664) ------------------------------------------------------------------
-    __device__ double computeErrorRate(Leaf<P>& nd, const double* parent_ring)
-    {
-        double matchedLen = (double)nd.totalSeeds + seedSize - 1;
-        matchedLen += nd.numRedeemSeed;
-        const double totalLen = (double)nd.currOverlapLen;
-        const double unmatchedLen = totalLen - matchedLen;
-        double currErrorRate = unmatchedLen / totalLen;
-        nd.globalErr = currErrorRate;
-        const uint32_t totalsize = nd.hist_size + 1;          // after the push_back
-        nd.hist_size = totalsize;
-        if(totalsize >= localK) {
-            const double old = parent_ring[(totalsize - localK) % 100];
-            currErrorRate = (currErrorRate * totalLen - old * (totalLen - localK)) / localK;
-        }
-        nd.localErr = currErrorRate;
-        return currErrorRate;
-    }
-
-    // ---- PrunedBySeedSupport (.cpp:491-563) ------------------------------------------------------------------
-    __device__ void PrunedBySeedSupport()
-    {
-        const uint64_t currSeedIdx = currentLength - seedSize;
-        const uint64_t indelOffset = seedSize + maxIndelSize;
-        const uint64_t smallSeedIdx = currSeedIdx <= indelOffset ? 0 : currSeedIdx - indelOffset;
-        const uint64_t largeSeedIdx = (currSeedIdx + indelOffset) >= (Lq - seedSize) ? (Lq - seedSize) : currSeedIdx + indelOffset;
-        for(uint32_t c = 0; c < n_nxt; ++c) {
-            Leaf<P>& leaf = nxt[c];
-            bool isNewSeedFound = false;
-            if(currentLength - leaf.lastOverlapLen > seedSize || currentLength - leaf.lastOverlapLen <= 1) {
-                const uint64_t preSeedIdx = leaf.lastSeedIdx;
-                isNewSeedFound = isSupportedByNewSeed(leaf, smallSeedIdx, largeSeedIdx);
-                if(isNewSeedFound) {
-                    if(currSeedIdx + (uint64_t)(int64_t)leaf.lastSeedIdxOffset - preSeedIdx > seedSize)
-                        leaf.numRedeemSeed += (seedSize - 1) * PacBioErrorRate;
-                    leaf.lastSeedIdxOffset = (int)leaf.lastSeedIdx - (int)currSeedIdx;
-                } else {
-                    const uint64_t v = currSeedIdx + (uint64_t)(int64_t)leaf.lastSeedIdxOffset - leaf.lastSeedIdx;
-                    if(v % seedSize == 1) leaf.numOfErrors++;
-                    else if(v > (uint64_t)seedSize - 1) leaf.numRedeemSeed += 1 - PacBioErrorRate;
-                }
-            } else
-                leaf.numRedeemSeed += 1 - PacBioErrorRate;
-            const double* pring = rings + (uint64_t)cur[leaf.parent].ring * 100;
-            const double currErrorRate = computeErrorRate(leaf, pring);
-            if(currErrorRate > errorRate) leaf.alive = 0;
-        }
-    }
-
-    // ---- isTerminated for one leaf (.cpp:825-878); path given as (words, len) + optional extra char ------------
-    __device__ void terminated_leaf(Leaf<P>& lf, const uint32_t* pw, uint32_t plen, int extra)
-    {
-        const bool fvalid = lf.flo <= lf.fhi, rvalid = lf.rlo <= lf.rhi;
-        const uint64_t i0 = (uint64_t)(lf.res_second > 0 ? lf.res_second : 0);
-        int hit = -1;
-        for(uint64_t i = i0; i <= (uint64_t)trg_len - (int)minOverlap; i++) {
-            const P* t = term + i * 4;
-            const bool isFwdTerminated = fvalid && lf.flo >= t[0] && lf.fhi <= t[1];
-            const bool isRvcTerminated = rvalid && lf.rlo >= t[2] && lf.rhi <= t[3];
-            if(isFwdTerminated || isRvcTerminated) {
-                hit = (int)i;
-                if(lf.res_first == -1) {
-                    if(n_results >= kMaxResults) { error = LRSC_WALK_ERR_RESULTS; return; }
-                    ++n_results;
-                    lf.res_first = (int)n_results;
-                }
-                lf.res_second = (int)i;
-            }
-        }
-        if(hit < 0) return;
-        // results.at(first - 1) = STresult: thread = getFullString() (+ target.substr(i + minOverlap) appended at the end)
-        WalkResultRec& r = results[lf.res_first - 1];
-        r.error_rate = lf.globalErr;
-        r.match_i = (uint32_t)hit;
-        uint32_t* dst = rpaths + (uint64_t)(lf.res_first - 1) * pathw;
-        const uint32_t nw = (plen + 15) >> 4;
-        for(uint32_t k = 0; k < nw; ++k) dst[k] = pw[k];
-        uint32_t len = plen;
-        if(extra >= 0) { path_set(dst, len, (uint32_t)extra); ++len; }
-        r.path_len = len;
-    }
-
-    // ---- one walk ----------------------------------------------------------------------------------------------
-    __device__ int run(uint32_t* out_len, uint32_t* out_words, uint32_t* out_match_i)
-    {
-        // --- interval "trees": compact the valid 9-mer entries (emplace_back order), introsort, chain by k-mer ---
-        auto build9 = [&](SortItem* it, uint32_t n_all, uint16_t* head, uint16_t* next) -> uint32_t {
-            uint32_t n = 0;
-            for(uint32_t i = 0; i < n_all; ++i)
-                if(it[i].key != kNoKey) { if(n != i) it[n] = it[i]; ++n; }
-            introsort(it, (int64_t)n);
-            for(uint32_t b = 0; b < 256; ++b) head[b] = 0xFFFFu;
-            // append in sorted order: chains keep the post-sort order of equal keys
-            uint16_t tail[256];
-            for(uint32_t j = 0; j < n; ++j) {
-                const uint32_t code = kmer_code(it[j].val);
-                const uint32_t hb = (code ^ (code >> 9)) & 255u;
-                next[j] = 0xFFFFu;
-                if(head[hb] == 0xFFFFu) head[hb] = (uint16_t)j; else next[tail[hb]] = (uint16_t)j;
-                tail[hb] = (uint16_t)j;
-            }
-            return n;
-        };
-        const uint32_t n9_all = Lq >= seedSize ? Lq - seedSize + 1 : 0;
-        n9f = build9(it9f, n9_all, head9f, next9f);
-        n9r = build9(it9r, n9_all, head9r, next9r);
-        for(uint32_t c = 0; c < 1024; ++c) head5[c] = 0xFFFFu;
-        const uint32_t n5 = Lq >= 5 ? Lq - 5 + 1 : 0;
-        for(uint32_t i = n5; i-- > 0;) {                       // prepend while walking backwards: ascending chains
-            if(flags5[i] == 0) continue;
-            uint32_t code = 0;
-            for(uint32_t t = 0; t < 5; ++t) code = (code << 2) | q[i + t];
-            next5[i] = head5[code];
-            head5[code] = (uint16_t)i;
-        }
-
-        // --- root (initialRootNode, .cpp:108-124; leafInfo ctor, .h:156-171) ---
-        n_ring_free = 0; n_path_free = 0;
-        for(uint32_t s = 32; s-- > 1;) { ring_free[n_ring_free++] = (uint8_t)s; path_free[n_path_free++] = (uint8_t)s; }
-        Leaf<P>& root = cur[0];
-        root.suf_lo = 0; root.suf_hi = 0;
-        for(uint32_t t = 0; t < initk; ++t) suf_push(root, q[t]);
-        find_suffix(root, initk);
-        root.lastOverlapLen = root.currOverlapLen = root.queryOverlapLen = initk;
-        currentLength = currentKmerSize = initk;
-        root.lastSeedIdx = (uint64_t)initk - seedSize;
-        root.totalSeeds = (uint64_t)initk - seedSize + 1;
-        root.numOfErrors = 0;
-        root.numRedeemSeed = 0;
-        root.localErr = 0; root.globalErr = 0; root.hist_size = 1;
-        root.lastSeedIdxOffset = 0;
-        root.res_first = -1; root.res_second = -1;
-        root.kmerFrequency = (int)(isize(root.flo, root.fhi) + isize(root.rlo, root.rhi));
-        root.tailLetter = q[initk - 1];
-        root.tailLetterCount = 0;
-        for(uint32_t t = initk; t-- > 0;) { if(q[t] == root.tailLetter) root.tailLetterCount++; else break; }
-        root.ring = 0; root.path = 0; root.parent = 0; root.ext = 0; root.alive = 1;
-        root.path_len = initk;
-        rings[0] = 0.0;
-        for(uint32_t t = 0; t < initk; ++t) path_set(paths, t, q[t]);
-        n_cur = 1; n_nxt = 0; n_results = 0;
-
-        // --- extendOverlap (.cpp:155-211) ---
-        while(n_cur != 0 && n_cur <= maxLeaves && currentLength <= maxLength) {
-            extendLeaves();
-            if(error) return error;
-            PrunedBySeedSupport();
-            uint32_t survivors = 0;
-            for(uint32_t c = 0; c < n_nxt; ++c) survivors += nxt[c].alive;
-            ++steps;
-            if(survivors > maxLeaves) {
-                // the frontier overflows: the loop ends after this isTerminated, no leaf state is needed any more
-                if(currentLength >= minLength)
-                    for(uint32_t c = 0; c < n_nxt; ++c) {
-                        if(!nxt[c].alive) continue;
-                        const Leaf<P>& par = cur[nxt[c].parent];
-                        terminated_leaf(nxt[c], paths + (uint64_t)par.path * pathw, par.path_len, (int)nxt[c].ext);
-                        if(error) return error;
-                    }
-                n_cur = survivors;
-                break;
-            }
-            // materialise the survivors: the first surviving child of a parent takes over its ring and path
-            // in place (SAINode::extend), further ones get copies (createChild)
-            uint8_t first_child[32];
-            for(uint32_t i = 0; i < n_cur; ++i) first_child[i] = 0xFF;
-            for(uint32_t c = 0; c < n_nxt; ++c)
-                if(nxt[c].alive && first_child[nxt[c].parent] == 0xFF) first_child[nxt[c].parent] = (uint8_t)(c & 0xFF);
-            bool has_child[32];
-            for(uint32_t i = 0; i < n_cur; ++i) { has_child[i] = false; }
-            for(uint32_t c = 0; c < n_nxt; ++c) if(nxt[c].alive) has_child[nxt[c].parent] = true;
-            for(uint32_t i = 0; i < n_cur; ++i) if(!has_child[i]) free_leaf_slots(cur[i]);
-            // copies first (they read the parent's buffers before the in-place child appends to them)
-            bool seen[32];
-            for(uint32_t i = 0; i < n_cur; ++i) seen[i] = false;
-            for(uint32_t c = 0; c < n_nxt; ++c) {
-                Leaf<P>& ch = nxt[c];
-                if(!ch.alive) continue;
-                const Leaf<P>& par = cur[ch.parent];
-                if(!seen[ch.parent]) { seen[ch.parent] = true; ch.ring = par.ring; ch.path = par.path; continue; }
-                ch.ring = ring_free[--n_ring_free];
-                ch.path = path_free[--n_path_free];
-                const double* src = rings + (uint64_t)par.ring * 100;
-                double* dst = rings + (uint64_t)ch.ring * 100;
-                for(uint32_t k = 0; k < 100; ++k) dst[k] = src[k];
-                const uint32_t* ps = paths + (uint64_t)par.path * pathw;
-                uint32_t* pd = paths + (uint64_t)ch.path * pathw;
-                const uint32_t nw = (par.path_len + 16) >> 4;
-                for(uint32_t k = 0; k < nw; ++k) pd[k] = ps[k];
-            }
-            uint32_t w = 0;
-            for(uint32_t c = 0; c < n_nxt; ++c) {
-                Leaf<P>& ch = nxt[c];
-                if(!ch.alive) continue;
-                rings[(uint64_t)ch.ring * 100 + (ch.hist_size - 1) % 100] = ch.globalErr;     // GlobalErrorRateRecord.push_back
-                path_set(paths + (uint64_t)ch.path * pathw, ch.path_len, ch.ext);
-                ch.path_len++;
-                nxt[w++] = ch;
-            }
-            // m_leaves = newLeaves
-            for(uint32_t i = 0; i < w; ++i) cur[i] = nxt[i];
-            n_cur = w;
-            if(currentLength >= minLength)
-                for(uint32_t i = 0; i < n_cur; ++i) {
-                    terminated_leaf(cur[i], paths + (uint64_t)cur[i].path * pathw, cur[i].path_len, -1);
-                    if(error) return error;
-                }
-        }
-
-        // --- findTheBestPath (.cpp:214-236) ---
-        if(n_results > 0) {
-            double minErrorRate = 1;
-            int best = -1;
-            for(uint32_t i = 0; i < n_results; ++i)
-                if(results[i].error_rate < minErrorRate) { minErrorRate = results[i].error_rate; best = (int)i; }
-            if(best < 0) return -4;
-            *out_len = results[best].path_len;
-            *out_match_i = results[best].match_i;
-            const uint32_t* src = rpaths + (uint64_t)best * pathw;
-            const uint32_t nw = (results[best].path_len + 15) >> 4;
-            for(uint32_t k = 0; k < nw; ++k) out_words[k] = src[k];
-            return 1;
-        }
-        if(n_cur == 0) return -1;                    // high error
-        else if(currentLength > maxLength) return -2;   // exceed search depth
-        else if(n_cur > maxLeaves) return -3;        // too much repeats
-        return -4;
-    }
-};
 
 template <bool WIDE>
 __global__ __launch_bounds__(64, 2) void walk_extend_kernel(FmIndexDev fm, ExtendArgs a)

@@ -292,12 +292,22 @@ def _fasta(results, pieces, reads, split):
     return "".join(correct), "".join(discard)
 
 
-@pytest.mark.parametrize("genome,cov,split", [(5, 90, 0), (5, 90, 1), (10, 90, 0)])
-def test_whole_path_nodp_matches_oracle_fasta(api, gpu_index, oracle, small_ds, genome, cov, split):
+@pytest.fixture(params=["device", "rounds"])
+def correct_mode(request, monkeypatch):
+    """device = the persistent per-read kernel (default); rounds = per-walk launches stitched on the host."""
+    if request.param == "rounds":
+        monkeypatch.setenv("LRSC_CORRECT_MODE", "rounds")
+    else:
+        monkeypatch.delenv("LRSC_CORRECT_MODE", raising=False)
+    return request.param
+
+
+@pytest.mark.parametrize("genome,cov,split,next_target", [(5, 90, 0, 1), (5, 90, 1, 1), (10, 90, 0, 1), (5, 90, 0, 3), (5, 90, 1, 2)])
+def test_whole_path_nodp_matches_oracle_fasta(api, gpu_index, oracle, small_ds, genome, cov, split, next_target, correct_mode):
     """correct.fa / discard.fa and every integer counter of PacBioSelfCorrectionResult, bit-identical to the
     CPU oracle (--nodp: failed walks copy the raw segment, PacBioSelfCorrectionProcess.cpp:146-147)."""
     p = api.params_default(genome, cov)
-    p.no_dp, p.split = 1, split
+    p.no_dp, p.split, p.next_target = 1, split, next_target
     ob, orb = oracle.bwt_load(small_ds.prefix + ".bwt"), oracle.bwt_load(small_ds.prefix + ".rbwt")
     want = oracle.correct_reads(ob, orb, p, small_ds.bases, small_ds.off)
     ctx = gpu_index.ctx(p, 0)
@@ -335,7 +345,7 @@ def rep_index(api, repeat_ds):
 
 
 @pytest.mark.parametrize("genome", [5, 10])
-def test_repeat_dataset_seeds_walks_and_fasta(api, rep_index, oracle, repeat_ds, genome):
+def test_repeat_dataset_seeds_walks_and_fasta(api, rep_index, oracle, repeat_ds, genome, correct_mode):
     p = api.params_default(genome, 90)
     p.no_dp = 1
     ob, orb = oracle.bwt_load(repeat_ds.prefix + ".bwt"), oracle.bwt_load(repeat_ds.prefix + ".rbwt")
