@@ -1206,6 +1206,13 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
     HIP_TRY(hipMemcpy(ro.data(), d_out.p, (size_t)n * sizeof(ReadOut), hipMemcpyDeviceToHost));
     std::vector<uint32_t> pieces(std::max<uint64_t>(piece_total, 1));
     if(piece_total) HIP_TRY(hipMemcpy(pieces.data(), d_pieces.p, (size_t)piece_total * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if(std::getenv("LRSC_CORRECT_PROFILE")) {
+        double c[4] = {0, 0, 0, 0};
+        for(uint32_t r = 0; r < n; ++r) for(int j = 0; j < 4; ++j) c[j] += (double)ro[r].cyc[j];
+        const double tot = c[0] + c[1] + c[2] + c[3];
+        std::fprintf(stderr, "[lrsc] correct kernel lane-ticks: prepare %.1f%%, trees+root %.1f%%, extension loop %.1f%%, stitch+other %.1f%% (%.3g ticks)\n",
+                     100 * c[0] / tot, 100 * c[1] / tot, 100 * c[2] / tot, 100 * c[3] / tot, tot);
+    }
     std::vector<uint64_t> dst_off(n + 1, 0);
     uint64_t n_pieces = 0;
     for(uint32_t r = 0; r < n; ++r) {

@@ -31,6 +31,7 @@ struct ReadOut {             // PacBioSelfCorrectionResult (PacBioSelfCorrection
     int64_t c[10];           // totalReadsLen, correctedLen, totalSeedNum, totalWalkNum, highErrorNum, exceedDepthNum,
                              // exceedLeaveNum, FMNum, DPNum, seedDis
     uint64_t steps;
+    uint64_t cyc[4];         // s_memtime ticks in: query + prepare, trees + root, extension loop, stitching (LRSC_CORRECT_PROFILE)
     uint32_t n_pieces, out_len, merge;
     int32_t error;
 };

@@ -39,6 +39,8 @@ __global__ __launch_bounds__(64, 2) void correct_reads_kernel(FmIndexDev fm, Cor
         int64_t correctedLen = 0, totalWalkNum = 0, highErrorNum = 0, exceedDepthNum = 0, exceedLeaveNum = 0, FMNum = 0, seedDis = 0;
         uint32_t out_len = 0, n_pieces = 0;
         int error = 0;
+        uint64_t cyc_prep = 0, cyc_stitch = 0;
+        R.cyc[1] = 0; R.cyc[2] = 0;
 
         if(n_seeds >= 2) {
             uint8_t* ws = a.workspace + rw.ws_off;
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(64, 2) void correct_reads_kernel(FmIndexDev fm, Cor
             uint8_t* q = ws + rw.o_query;
             uint32_t* best = reinterpret_cast<uint32_t*>(ws + rw.o_best);
             W.q = q;
-            W.n_rank = 0; W.n_blk = 0; W.steps = 0; W.error = 0;
+            W.n_rank = 0; W.n_blk = 0; W.steps = 0; W.error = 0; W.cyc_setup = 0; W.cyc_loop = 0;
 
             // pieceVec.push_back(seedVec[0])
             piece_start[n_pieces++] = 0;
@@ -84,7 +86,9 @@ __global__ __launch_bounds__(64, 2) void correct_reads_kernel(FmIndexDev fm, Cor
             int next = 0, firstType = 0;
             const int min_SA = a.pb_coverage > 60 ? (int)((a.pb_coverage / 60) * 3) : 3;
 
+            const uint64_t t_all0 = __builtin_readcyclecounter();
             while(it < n_seeds && !error) {
+                const uint64_t t0 = __builtin_readcyclecounter();
                 const int32_t* T = seeds + (uint64_t)(it + (uint32_t)next) * kSeedInts;
                 const int T_start = T[0], T_len = T[1];
                 const bool T_isRepeat = (T[3] & 1) != 0;
@@ -123,6 +127,8 @@ __global__ __launch_bounds__(64, 2) void correct_reads_kernel(FmIndexDev fm, Cor
                 W.minLength = (uint64_t)((0.8 * (interval - 20)) + (double)(2 * (uint64_t)k));
                 W.n_term = (uint32_t)trg_len - a.min_overlap + 1;
                 uint32_t plen = 0, mi = 0;
+                const uint64_t t1 = __builtin_readcyclecounter();
+                cyc_prep += t1 - t0;
                 const int code = W.run(&plen, best, &mi);
                 if(code <= LRSC_WALK_ERR_CHILDREN) { error = code; break; }
                 if(next == 0) firstType = code;
@@ -192,10 +198,13 @@ __global__ __launch_bounds__(64, 2) void correct_reads_kernel(FmIndexDev fm, Cor
             }
             n_rank = W.n_rank; n_blk = W.n_blk;
             R.steps = W.steps;
+            R.cyc[1] = W.cyc_setup; R.cyc[2] = W.cyc_loop;
+            cyc_stitch = __builtin_readcyclecounter() - t_all0 - cyc_prep - W.cyc_setup - W.cyc_loop;
         } else
             R.steps = 0;
         R.c[0] = rlen; R.c[1] = correctedLen; R.c[2] = n_seeds; R.c[3] = totalWalkNum; R.c[4] = highErrorNum;
         R.c[5] = exceedDepthNum; R.c[6] = exceedLeaveNum; R.c[7] = FMNum; R.c[8] = 0; R.c[9] = seedDis;
+        R.cyc[0] = cyc_prep; R.cyc[3] = cyc_stitch;
         R.n_pieces = n_pieces; R.out_len = out_len; R.merge = n_pieces != 0; R.error = error;
     }
     flush_counters(a.ctr, n_rank, n_blk);

@@ -131,6 +131,7 @@ struct Walk {
     uint8_t ring_free[32], path_free[32]; uint32_t n_ring_free, n_path_free;
     uint32_t n_rank, n_blk;
     uint64_t steps;
+    uint64_t cyc_setup, cyc_loop;     // profiling: ticks spent building the trees/root and in the extension loop
     int error;
 
     __device__ __forceinline__ IvT<P> upd(const StrandC<P>& s, uint32_t c, IvT<P> iv) { n_rank += 2; return update_interval<WIDE>(s, c, iv, mtab, n_blk); }
@@ -497,6 +498,7 @@ struct Walk {
     // ---- one walk ----------------------------------------------------------------------------------------------
     __device__ int run(uint32_t* out_len, uint32_t* out_words, uint32_t* out_match_i)
     {
+        const uint64_t t_run0 = __builtin_readcyclecounter();
         // --- interval "trees": compact the valid 9-mer entries (emplace_back order), introsort, chain by k-mer ---
         auto build9 = [&](SortItem* it, uint32_t n_all, uint16_t* head, uint16_t* next) -> uint32_t {
             uint32_t n = 0;
@@ -554,6 +556,8 @@ struct Walk {
         for(uint32_t t = 0; t < initk; ++t) path_set(paths, t, q[t]);
         n_cur = 1; n_nxt = 0; n_results = 0;
 
+        const uint64_t t_run1 = __builtin_readcyclecounter();
+        cyc_setup += t_run1 - t_run0;
         // --- extendOverlap (.cpp:155-211) ---
         while(n_cur != 0 && n_cur <= maxLeaves && currentLength <= maxLength) {
             extendLeaves();
@@ -621,6 +625,7 @@ struct Walk {
                 }
         }
 
+        cyc_loop += __builtin_readcyclecounter() - t_run1;
         // --- findTheBestPath (.cpp:214-236) ---
         if(n_results > 0) {
             double minErrorRate = 1;
