@@ -250,6 +250,26 @@ int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* batch, lrsc_read_result* resul
                        uint64_t piece_cap, char* out, uint64_t out_cap, uint64_t* n_pieces, uint64_t* out_used);
 int lrsc_ctx_get_params(const lrsc_ctx* ctx, lrsc_params* out);
 
+/* ---- DP/MSA fallback: Overlapper::extendMatch ------------------------------------------------------------- */
+/* One banded alignment (Thirdparty/overlapper.cpp:421-701): s1 = seq[s1_off .. +s1_len) (the query, DP columns),
+ * s2 = seq[s2_off .. +s2_len) (DP rows); start1/start2 = the seed match that centres the band. */
+typedef struct lrsc_dp_job {
+    uint64_t s1_off, s2_off;
+    uint32_t s1_len, s2_len;
+    int32_t  start1, start2;
+} lrsc_dp_job;
+typedef struct lrsc_dp_result {      /* SequenceOverlap (Thirdparty/overlapper.h:69-125) */
+    int32_t  match0_start, match0_end, match1_start, match1_end;
+    int32_t  score, edit_distance, total_columns;
+    uint32_t cigar_len;              /* EXPANDED cigar ('M','I','D' per column) at cigar_arena + cigar_off */
+    uint64_t cigar_off;
+} lrsc_dp_result;
+/* n alignments on the device, one wavefront each.  LRSC_ERR_CAPACITY (with *arena_used = bytes needed) if
+ * arena_cap is too small. */
+int lrsc_dp_align(lrsc_ctx* ctx, const char* seq, uint64_t seq_len, const lrsc_dp_job* jobs, uint32_t n, int band_width,
+                  int match_score, int gap_penalty, int mismatch_penalty, lrsc_dp_result* results, char* cigar_arena,
+                  uint64_t arena_cap, uint64_t* arena_used);
+
 /* ---- DP/MSA fallback building blocks ------------------------------------------------------------------- */
 /* LongReadOverlap::retrieveStr's LF-walks (PacBio/LongReadOverlap.cpp:696-749): job i starts at BWT row
  * rows[i] of strand[i] and emits at most max_steps[i] characters (stops at a '$' row).  Job i's characters
@@ -265,7 +285,7 @@ typedef struct lrsc_kernel_stats {
     uint64_t block_loads;       /* rank-block loads (lower-1/upper in one block count 1) */
     uint64_t table_loads;       /* k-mer interval table look-ups (one 64-byte line each)  */
 } lrsc_kernel_stats;
-enum { LRSC_K_RANK = 0, LRSC_K_FIND = 1, LRSC_K_GRID = 2, LRSC_K_SEEDS = 3, LRSC_K_EXTEND = 4, LRSC_K_LF = 5, LRSC_K_COUNT = 6 };
+enum { LRSC_K_RANK = 0, LRSC_K_FIND = 1, LRSC_K_GRID = 2, LRSC_K_SEEDS = 3, LRSC_K_EXTEND = 4, LRSC_K_LF = 5, LRSC_K_DP = 6, LRSC_K_MSA = 7, LRSC_K_COUNT = 8 };
 int lrsc_ctx_stats(lrsc_ctx* ctx, int kernel, lrsc_kernel_stats* out);
 int lrsc_ctx_stats_reset(lrsc_ctx* ctx);
 /* Block until everything queued on the ctx stream is done. */

@@ -82,6 +82,16 @@ class WalkResult(C.Structure):
     _fields_ = [("code", C.c_int32), ("steps", C.c_uint32), ("out_off", C.c_uint64), ("out_len", C.c_uint32), ("pad", C.c_uint32)]
 
 
+class DpJob(C.Structure):
+    _fields_ = [("s1_off", C.c_uint64), ("s2_off", C.c_uint64), ("s1_len", C.c_uint32), ("s2_len", C.c_uint32),
+                ("start1", C.c_int32), ("start2", C.c_int32)]
+
+
+class DpResult(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("match0_start", "match0_end", "match1_start", "match1_end", "score", "edit_distance",
+                                         "total_columns")] + [("cigar_len", C.c_uint32), ("cigar_off", C.c_uint64)]
+
+
 class ReadResult(C.Structure):
     _fields_ = [("merge", C.c_int32), ("n_pieces", C.c_uint32), ("piece_first", C.c_uint64)] + [
         (n, C.c_int64) for n in ("total_reads_len", "corrected_len", "total_seed_num", "total_walk_num", "high_error_num",
@@ -98,7 +108,7 @@ class KernelStats(C.Structure):
     ]
 
 
-K_RANK, K_FIND, K_GRID, K_SEEDS, K_EXTEND, K_LF = range(6)
+K_RANK, K_FIND, K_GRID, K_SEEDS, K_EXTEND, K_LF, K_DP, K_MSA = range(8)
 SEED_DTYPE = np.dtype([("start", "<i4"), ("len", "<i4"), ("max_freq", "<i4"), ("repeat", "<i4"), ("start_k", "<i4"),
                        ("end_k", "<i4"), ("start_freq", "<i4"), ("end_freq", "<i4")])
 BWT, RBWT = 0, 1
@@ -347,6 +357,38 @@ class Ctx:
                                                  _ptr(lens)), "lrsc_lf_walk")
         buf = out.tobytes()
         return [buf[int(off[i]): int(off[i]) + int(lens[i])].decode() for i in range(rows.size)]
+
+    def dp_align(self, pairs, band_width=200, scores=(1, -1, -8)):
+        """pairs: list of (s1, s2, start1, start2) -> list of dicts like the oracle's extend_match (compact cigar)."""
+        n = len(pairs)
+        jobs = (DpJob * n)()
+        parts, off = [], 0
+        for i, (s1, s2, a, b) in enumerate(pairs):
+            j = jobs[i]
+            j.s1_off, j.s1_len = off, len(s1); off += len(s1)
+            j.s2_off, j.s2_len = off, len(s2); off += len(s2)
+            j.start1, j.start2 = a, b
+            parts += [s1, s2]
+        seq = "".join(parts).encode()
+        res = (DpResult * n)()
+        cap = len(seq) + n + 64
+        arena = C.create_string_buffer(cap)
+        used = C.c_uint64()
+        self.api.check(self.api.lib.lrsc_dp_align(self.h, seq, len(seq), jobs, n, band_width, scores[0], scores[1], scores[2], res,
+                                                  arena, cap, C.byref(used)), "lrsc_dp_align")
+        out = []
+        for r in res:
+            ops = arena.raw[r.cigar_off: r.cigar_off + r.cigar_len].decode()
+            cig, k = [], 0
+            while k < len(ops):
+                e = k
+                while e < len(ops) and ops[e] == ops[k]:
+                    e += 1
+                cig.append(f"{e - k}{ops[k]}")
+                k = e
+            out.append(dict(m0s=r.match0_start, m0e=r.match0_end, m1s=r.match1_start, m1e=r.match1_end, score=r.score,
+                            edit=r.edit_distance, cols=r.total_columns, cigar="".join(cig)))
+        return out
 
     def extend_walks(self, walks):
         """walks: list of (src, path, trg, dis, init_kmer, max_overlap, min_sa).  -> list of (code, mergedSeq, steps)."""

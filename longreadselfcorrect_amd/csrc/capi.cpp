@@ -23,6 +23,7 @@
 #include "kernels.h"
 #include "extend.h"
 #include "correct_dev.h"
+#include "dp_dev.h"
 #include "introsort_emul.h"
 
 using namespace lrsc;
@@ -1245,5 +1246,93 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
         HIP_TRY(hipMemcpyAsync(out, d_dst.p, used, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
+    return LRSC_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// DP/MSA fallback
+// ---------------------------------------------------------------------------------------
+static int encode_acgt(const char* seq, uint64_t n, std::vector<uint8_t>& codes)
+{
+    codes.resize(n);
+    for(uint64_t i = 0; i < n; ++i) {
+        switch(seq[i]) {
+            case 'A': codes[i] = 0; break; case 'C': codes[i] = 1; break; case 'G': codes[i] = 2; break; case 'T': codes[i] = 3; break;
+            default: return fail(LRSC_ERR_ARG, "sequence contains a base other than A,C,G,T");
+        }
+    }
+    return LRSC_OK;
+}
+
+static uint32_t dp_wave_count(const lrsc_ctx* ctx)
+{
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    return (uint32_t)cus * 8u;
+}
+
+extern "C" int lrsc_dp_align(lrsc_ctx* ctx, const char* seq, uint64_t seq_len, const lrsc_dp_job* jobs, uint32_t n, int band_width,
+                             int match_score, int gap_penalty, int mismatch_penalty, lrsc_dp_result* results, char* cigar_arena,
+                             uint64_t arena_cap, uint64_t* arena_used)
+{
+    if(!ctx || (!jobs && n) || (!results && n) || !arena_used || (!seq && seq_len)) return fail(LRSC_ERR_ARG, "null");
+    *arena_used = 0;
+    if(n == 0) return LRSC_OK;
+    if(band_width < 2 || (band_width / 2) * 2 + 1 > (int)kDpMaxBand) return fail(LRSC_ERR_UNSUPPORTED, "band_width must be 2..254");
+    if(gap_penalty > 0) return fail(LRSC_ERR_ARG, "gap_penalty must be <= 0");
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<uint8_t> codes;
+    int st = encode_acgt(seq, seq_len, codes);
+    if(st != LRSC_OK) return st;
+    std::vector<DpJob> dj(n);
+    uint64_t ops_total = 0;
+    uint32_t max1 = 1, max2 = 1;
+    for(uint32_t i = 0; i < n; ++i) {
+        const lrsc_dp_job& j = jobs[i];
+        if(j.s1_off + j.s1_len > seq_len || j.s2_off + j.s2_len > seq_len) return fail(LRSC_ERR_ARG, "dp job: sequence out of range");
+        if(j.s1_len > kDpMaxSeq || j.s2_len > kDpMaxSeq) return fail(LRSC_ERR_UNSUPPORTED, "dp job: sequence too long");
+        DpJob& d = dj[i];
+        d.s1_off = j.s1_off; d.s2_off = j.s2_off; d.s1_len = j.s1_len; d.s2_len = j.s2_len; d.start1 = j.start1; d.start2 = j.start2;
+        d.skip = 0; d.pad = 0; d.ops_off = ops_total;
+        ops_total += (uint64_t)j.s1_len + j.s2_len + 1;
+        max1 = std::max(max1, j.s1_len); max2 = std::max(max2, j.s2_len);
+    }
+    if(((max1 + 2 + 3) & ~3u) + max2 + 8 > 64 * 1024) return fail(LRSC_ERR_UNSUPPORTED, "dp job: s1 + s2 must fit the 64 KB LDS stage");
+    const uint32_t n_waves = std::min<uint32_t>(dp_wave_count(ctx), n);
+    DevBuf<uint8_t> d_codes, d_ops, d_trace;
+    DevBuf<DpJob> d_jobs;
+    DevBuf<DpAlignOut> d_out;
+    DpAlignArgs a{};
+    a.trace_stride = (uint64_t)(max1 + 17) * kDpTraceStride;
+    HIP_TRY(d_codes.reserve(std::max<uint64_t>(seq_len, 1)));
+    HIP_TRY(d_ops.reserve(ops_total));
+    HIP_TRY(d_trace.reserve(a.trace_stride * n_waves));
+    HIP_TRY(d_jobs.reserve(n));
+    HIP_TRY(d_out.reserve(n));
+    HIP_TRY(hipMemcpyAsync(d_codes.p, codes.data(), seq_len, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_jobs.p, dj.data(), (size_t)n * sizeof(DpJob), hipMemcpyHostToDevice, ctx->stream));
+    a.codes = d_codes.p; a.jobs = d_jobs.p; a.n_jobs = n; a.band_width = (uint32_t)band_width;
+    a.match_score = match_score; a.gap_penalty = gap_penalty; a.mismatch_penalty = mismatch_penalty;
+    a.ops = d_ops.p; a.out = d_out.p; a.trace = d_trace.p; a.max_s1 = max1; a.max_s2 = max2;
+    st = timed_launch(ctx, LRSC_K_DP, [&]() { return launch_dp_align(a, n_waves, ctx->stream); });
+    if(st != LRSC_OK) return st;
+    std::vector<DpAlignOut> out(n);
+    std::vector<uint8_t> ops(ops_total);
+    HIP_TRY(hipMemcpy(out.data(), d_out.p, (size_t)n * sizeof(DpAlignOut), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ops.data(), d_ops.p, ops_total, hipMemcpyDeviceToHost));
+    uint64_t used = 0;
+    for(uint32_t i = 0; i < n; ++i) {
+        const DpAlignOut& o = out[i];
+        if(o.n_ops == 0xFFFFFFFFu) return fail(LRSC_ERR_DEVICE, "dp_align: traceback left the band");
+        lrsc_dp_result& r = results[i];
+        r.match0_start = o.m0s; r.match0_end = o.m0e; r.match1_start = o.m1s; r.match1_end = o.m1e;
+        r.score = o.score; r.edit_distance = o.edit_distance; r.total_columns = o.total_columns;
+        r.cigar_len = o.n_ops; r.cigar_off = used;
+        if(cigar_arena && used + o.n_ops <= arena_cap)
+            for(uint32_t t = 0; t < o.n_ops; ++t) cigar_arena[used + t] = (char)ops[dj[i].ops_off + o.n_ops - 1 - t];
+        used += o.n_ops;
+    }
+    *arena_used = used;
+    if(used > arena_cap || (!cigar_arena && used)) return fail(LRSC_ERR_CAPACITY, "cigar arena too small");
     return LRSC_OK;
 }

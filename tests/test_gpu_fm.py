@@ -408,3 +408,68 @@ def test_lf_walk_matches_oracle(gpu_ctx, oracle, small_ds):
                 idx = ob.pc(c) + int(ob.occ(np.frombuffer(c.encode(), dtype=np.uint8), np.array([idx - 1], dtype=np.int64))[0])
             assert g == "".join(want)
         ob.close()
+
+
+# ---- DP/MSA fallback: Overlapper::extendMatch --------------------------------------------------------------------
+def _mutate(rng, s, sub, ins, dele):
+    out = []
+    for c in s:
+        u = rng.random()
+        if u < dele:
+            continue
+        if u < dele + sub:
+            c = "ACGT"[rng.integers(4)]
+        out.append(c)
+        while rng.random() < ins:
+            out.append("ACGT"[rng.integers(4)])
+    return "".join(out)
+
+
+def _dp_pairs(rng, small_ds, n):
+    """(s1, s2, start1, start2) the way retrieveMatches calls extendMatch (LongReadOverlap.cpp:635-643): forward pairs
+    share their first k-mer, reverse pairs their last one; error profiles from identical to hopeless, homopolymer runs,
+    short / truncated s2 (the LF-walk hit a '$'), s2 longer than the band."""
+    g = small_ds.genome.tobytes().decode()
+    pairs = []
+    for t in range(n):
+        L = int(rng.integers(30, 420))
+        p = int(rng.integers(0, len(g) - 2 * L - 50))
+        q = g[p: p + L]
+        if t % 7 == 3:                                    # homopolymer-rich query
+            q = "".join(c * int(rng.integers(1, 5)) for c in q[: L // 2])
+        k = 17
+        err = [(0, 0, 0), (0.01, 0.03, 0.02), (0.015, 0.09, 0.045), (0.05, 0.15, 0.1), (0.3, 0.3, 0.3)][t % 5]
+        if t % 2 == 0:                                    # forward: same first k-mer, s2 runs ~1.1 |q| + 20 or stops early
+            tail = _mutate(rng, q[k:] + g[p + L: p + L + 60], *err)
+            m = int(len(q) * 1.1 + 20) if t % 3 else int(rng.integers(k, len(q)))
+            s2 = (q[:k] + tail)[:m]
+            pairs.append((q, s2, 0, 0))
+        else:                                             # reverse: same last k-mer
+            head = _mutate(rng, g[max(p - 60, 0): p] + q[:-k], *err)
+            m = int(len(q) * 1.1 + 20) if t % 3 else int(rng.integers(k, len(q)))
+            s2 = (head + q[-k:])[-m:]
+            pairs.append((q, s2, len(q) - k, len(s2) - k))
+    # the band (201) cut by both matrix edges, and one-column / one-row corner cases
+    pairs += [("ACGTACGTACGTACGTACGT", "ACGTACGTACGTACGTACGT", 0, 0), ("A" * 40, "A" * 25, 0, 0), ("ACGT" * 80, "ACGT" * 20, 0, 0),
+              ("ACGT" * 20, "ACGT" * 100, 0, 0), ("ACGTTGCA" * 4, "T", 0, 0), ("G", "ACGTTGCA" * 4, 0, 0),
+              ("ACGT" * 90, "TTGCA" * 90, 343, 433)]
+    return pairs
+
+
+def test_dp_align_matches_oracle_extend_match(gpu_ctx, oracle, small_ds):
+    """Every field of SequenceOverlap and the cigar, bit-identical to the oracle's extend_match (itself checked against
+    the reference's overlapper.cpp object code in tests/test_oracle_vs_ref.py)."""
+    rng = np.random.default_rng(77)
+    pairs = _dp_pairs(rng, small_ds, 240)
+    got = gpu_ctx.dp_align(pairs)
+    n_gapped = 0
+    for (s1, s2, a, b), g in zip(pairs, got):
+        want = oracle.extend_match(s1, s2, a, b)
+        assert g == want, (s1, s2, a, b)
+        n_gapped += ("I" in want["cigar"]) + ("D" in want["cigar"])
+    assert n_gapped > 100
+    for bw in (2, 11, 64, 254):                           # other band widths: the band edges move through the matrix
+        sub = pairs[:40] + pairs[-7:]
+        got = gpu_ctx.dp_align(sub, band_width=bw, scores=(2, -3, -5))
+        for (s1, s2, a, b), g in zip(sub, got):
+            assert g == oracle.extend_match(s1, s2, a, b, bandwidth=bw, scores=(2, -3, -5)), (bw, s1, s2, a, b)
