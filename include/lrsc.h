@@ -270,6 +270,28 @@ int lrsc_dp_align(lrsc_ctx* ctx, const char* seq, uint64_t seq_len, const lrsc_d
                   int match_score, int gap_penalty, int mismatch_penalty, lrsc_dp_result* results, char* cigar_arena,
                   uint64_t arena_cap, uint64_t* arena_used);
 
+/* ---- DP/MSA fallback: buildMultipleAlignment + calculateBaseConsensus ---------------------------------------- */
+/* One correctByMSAlignment-style call (PacBio/LongReadOverlap.cpp:17-55 + Thirdparty/multiple_alignment.cpp:517-594):
+ * query = seq[seq_off .. +len); reads overlapping its first / last kmer_len bases are retrieved from the index
+ * (at most params.pb_coverage rows per interval), aligned to the query (band 200, +1/-1/-8), filtered by
+ * min_overlap / min_identity, piled up and the base consensus (min_call_coverage, no trimming) is called. */
+typedef struct lrsc_msa_query {
+    uint64_t seq_off;
+    uint32_t len, kmer_len;
+    uint32_t min_overlap;
+    int32_t  min_call_coverage;
+    double   min_identity;
+} lrsc_msa_query;
+typedef struct lrsc_msa_result {
+    uint32_t n_rows;             /* MultipleAlignment::getNumRows(): 1 + accepted overlaps                    */
+    uint32_t n_retrieved;        /* strings LF-walked out of the index                                         */
+    uint32_t cons_len;           /* consensus at arena + cons_off                                              */
+    uint32_t pad;
+    uint64_t cons_off;
+} lrsc_msa_result;
+int lrsc_dp_consensus(lrsc_ctx* ctx, const char* seq, uint64_t seq_len, const lrsc_msa_query* queries, uint32_t n,
+                      lrsc_msa_result* results, char* arena, uint64_t arena_cap, uint64_t* arena_used);
+
 /* ---- DP/MSA fallback building blocks ------------------------------------------------------------------- */
 /* LongReadOverlap::retrieveStr's LF-walks (PacBio/LongReadOverlap.cpp:696-749): job i starts at BWT row
  * rows[i] of strand[i] and emits at most max_steps[i] characters (stops at a '$' row).  Job i's characters

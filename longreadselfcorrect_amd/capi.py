@@ -92,6 +92,16 @@ class DpResult(C.Structure):
                                          "total_columns")] + [("cigar_len", C.c_uint32), ("cigar_off", C.c_uint64)]
 
 
+class MsaQuery(C.Structure):
+    _fields_ = [("seq_off", C.c_uint64), ("len", C.c_uint32), ("kmer_len", C.c_uint32), ("min_overlap", C.c_uint32),
+                ("min_call_coverage", C.c_int32), ("min_identity", C.c_double)]
+
+
+class MsaResult(C.Structure):
+    _fields_ = [("n_rows", C.c_uint32), ("n_retrieved", C.c_uint32), ("cons_len", C.c_uint32), ("pad", C.c_uint32),
+                ("cons_off", C.c_uint64)]
+
+
 class ReadResult(C.Structure):
     _fields_ = [("merge", C.c_int32), ("n_pieces", C.c_uint32), ("piece_first", C.c_uint64)] + [
         (n, C.c_int64) for n in ("total_reads_len", "corrected_len", "total_seed_num", "total_walk_num", "high_error_num",
@@ -168,6 +178,10 @@ class Lrsc:
         L.lrsc_find_kmers.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]
         L.lrsc_kmer_grid.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
                                      C.c_void_p, C.c_void_p, C.c_void_p]
+        L.lrsc_dp_align.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.lrsc_dp_consensus.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64,
+                                        C.POINTER(C.c_uint64)]
         L.lrsc_batch_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
         L.lrsc_batch_destroy.argtypes = [C.c_void_p]
         L.lrsc_batch_destroy.restype = None
@@ -389,6 +403,22 @@ class Ctx:
             out.append(dict(m0s=r.match0_start, m0e=r.match0_end, m1s=r.match1_start, m1e=r.match1_end, score=r.score,
                             edit=r.edit_distance, cols=r.total_columns, cigar="".join(cig)))
         return out
+
+    def dp_consensus(self, queries):
+        """queries: list of (query, kmer_len, min_overlap, min_identity, min_call_coverage) -> list of (rows, consensus, retrieved)."""
+        n = len(queries)
+        qs = (MsaQuery * n)()
+        off = 0
+        for i, (q, k, mo, mi, mc) in enumerate(queries):
+            qs[i].seq_off, qs[i].len, qs[i].kmer_len, qs[i].min_overlap, qs[i].min_identity, qs[i].min_call_coverage = off, len(q), k, mo, mi, mc
+            off += len(q)
+        seq = "".join(q[0] for q in queries).encode()
+        res = (MsaResult * n)()
+        cap = 2 * len(seq) + 256 * n + 64
+        arena = C.create_string_buffer(cap)
+        used = C.c_uint64()
+        self.api.check(self.api.lib.lrsc_dp_consensus(self.h, seq, len(seq), qs, n, res, arena, cap, C.byref(used)), "lrsc_dp_consensus")
+        return [(r.n_rows, arena.raw[r.cons_off: r.cons_off + r.cons_len].decode(), r.n_retrieved) for r in res]
 
     def extend_walks(self, walks):
         """walks: list of (src, path, trg, dis, init_kmer, max_overlap, min_sa).  -> list of (code, mergedSeq, steps)."""

@@ -1293,7 +1293,7 @@ extern "C" int lrsc_dp_align(lrsc_ctx* ctx, const char* seq, uint64_t seq_len, c
         if(j.s1_len > kDpMaxSeq || j.s2_len > kDpMaxSeq) return fail(LRSC_ERR_UNSUPPORTED, "dp job: sequence too long");
         DpJob& d = dj[i];
         d.s1_off = j.s1_off; d.s2_off = j.s2_off; d.s1_len = j.s1_len; d.s2_len = j.s2_len; d.start1 = j.start1; d.start2 = j.start2;
-        d.skip = 0; d.pad = 0; d.ops_off = ops_total;
+        d.mode = 0; d.req = 0; d.ops_off = ops_total;
         ops_total += (uint64_t)j.s1_len + j.s2_len + 1;
         max1 = std::max(max1, j.s1_len); max2 = std::max(max2, j.s2_len);
     }
@@ -1311,7 +1311,7 @@ extern "C" int lrsc_dp_align(lrsc_ctx* ctx, const char* seq, uint64_t seq_len, c
     HIP_TRY(d_out.reserve(n));
     HIP_TRY(hipMemcpyAsync(d_codes.p, codes.data(), seq_len, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(d_jobs.p, dj.data(), (size_t)n * sizeof(DpJob), hipMemcpyHostToDevice, ctx->stream));
-    a.codes = d_codes.p; a.jobs = d_jobs.p; a.n_jobs = n; a.band_width = (uint32_t)band_width;
+    a.codes = d_codes.p; a.strings = d_codes.p; a.jobs = d_jobs.p; a.n_jobs = n; a.band_width = (uint32_t)band_width;
     a.match_score = match_score; a.gap_penalty = gap_penalty; a.mismatch_penalty = mismatch_penalty;
     a.ops = d_ops.p; a.out = d_out.p; a.trace = d_trace.p; a.max_s1 = max1; a.max_s2 = max2;
     st = timed_launch(ctx, LRSC_K_DP, [&]() { return launch_dp_align(a, n_waves, ctx->stream); });
@@ -1334,5 +1334,155 @@ extern "C" int lrsc_dp_align(lrsc_ctx* ctx, const char* seq, uint64_t seq_len, c
     }
     *arena_used = used;
     if(used > arena_cap || (!cigar_arena && used)) return fail(LRSC_ERR_CAPACITY, "cigar arena too small");
+    return LRSC_OK;
+}
+
+// The DP stage for a set of requests whose queries are already on the device: seeds -> (chunked by memory)
+// retrieve -> align -> MSA.  Results stay on the device (d_msa[i], consensus codes at d_cons + reqs[i].cons_off).
+struct DpStage {
+    DevBuf<DpRequest> d_reqs;
+    DevBuf<DpMsaOut> d_msa;
+    DevBuf<uint8_t> d_cons, d_strings, d_ops, d_trace;
+    DevBuf<DpJob> d_jobs;
+    DevBuf<DpAlignOut> d_align;
+    uint64_t cons_total = 0, n_strings = 0;
+
+    int run(lrsc_ctx* ctx, const uint8_t* d_query_codes, std::vector<DpRequest>& reqs)
+    {
+        const uint32_t n = (uint32_t)reqs.size();
+        n_strings = 0; cons_total = 0;
+        if(n == 0) return LRSC_OK;
+        for(DpRequest& r : reqs) {
+            if(r.k == 0 || r.lq < r.k) return fail(LRSC_ERR_ARG, "dp request: kmer_len must satisfy 1 <= kmer_len <= query length");
+            r.max_len = (uint32_t)(size_t)(r.lq * 1.1 + 20);                 // LongReadOverlap.cpp:618
+            r.str_cap = (std::max(r.max_len, r.k) + 3) & ~3u;
+            r.ops_cap = (r.lq + r.str_cap + 1 + 3) & ~3u;
+            r.cons_cap = dp_msa_columns(r.lq);
+            r.cons_off = cons_total;
+            cons_total += r.cons_cap;
+            if(((r.lq + 2 + 3) & ~3u) + r.str_cap + 8 > 64 * 1024) return fail(LRSC_ERR_UNSUPPORTED, "dp request: query longer than ~30 kb");
+            if(dp_msa_lds_bytes(r.lq, r.str_cap, r.ops_cap, r.coverage) > 160 * 1024)
+                return fail(LRSC_ERR_UNSUPPORTED, "dp request: query too long for the LDS-resident multiple alignment (~5 kb)");
+        }
+        HIP_TRY(d_reqs.reserve(n));
+        HIP_TRY(d_msa.reserve(n));
+        HIP_TRY(d_cons.reserve(cons_total));
+        HIP_TRY(hipMemcpyAsync(d_reqs.p, reqs.data(), (size_t)n * sizeof(DpRequest), hipMemcpyHostToDevice, ctx->stream));
+        DpPipeArgs a{};
+        a.codes = d_query_codes; a.reqs = d_reqs.p; a.n_reqs = n; a.ctr = ctx->d_ctr;
+        int st = timed_launch(ctx, LRSC_K_LF, [&]() { return launch_dp_seeds(ctx->fm, a, ctx->stream); });
+        if(st != LRSC_OK) return st;
+        HIP_TRY(hipMemcpy(reqs.data(), d_reqs.p, (size_t)n * sizeof(DpRequest), hipMemcpyDeviceToHost));
+
+        uint64_t budget = 16ull << 30;
+        if(const char* e = std::getenv("LRSC_DP_CHUNK_MB")) budget = std::max<uint64_t>(1, (uint64_t)std::atoll(e)) << 20;
+        const uint32_t n_waves = dp_wave_count(ctx);
+        uint32_t begin = 0;
+        while(begin < n) {
+            uint32_t end = begin, max1 = 1, max2 = 1, lds = 0;
+            uint64_t jobs = 0, sbytes = 0, obytes = 0;
+            while(end < n) {
+                DpRequest& r = reqs[end];
+                r.n_str = r.cnt[0] + r.cnt[1] + r.cnt[2] + r.cnt[3];
+                const uint64_t sb = (uint64_t)r.n_str * r.str_cap, ob = (uint64_t)r.n_str * r.ops_cap;
+                if(end > begin && sbytes + obytes + sb + ob + (jobs + r.n_str) * (sizeof(DpJob) + sizeof(DpAlignOut)) > budget) break;
+                r.job_first = jobs; r.str_off = sbytes; r.ops_off = obytes;
+                jobs += r.n_str; sbytes += sb; obytes += ob;
+                max1 = std::max(max1, r.lq); max2 = std::max(max2, r.str_cap);
+                lds = std::max(lds, dp_msa_lds_bytes(r.lq, r.str_cap, r.ops_cap, r.coverage));
+                ++end;
+            }
+            if(jobs >= (1ull << 32)) return fail(LRSC_ERR_UNSUPPORTED, "dp chunk: too many alignments");
+            const uint32_t nc = end - begin;
+            HIP_TRY(hipMemcpyAsync(d_reqs.p + begin, reqs.data() + begin, (size_t)nc * sizeof(DpRequest), hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(d_strings.reserve(std::max<uint64_t>(sbytes, 64)));
+            HIP_TRY(d_ops.reserve(std::max<uint64_t>(obytes, 64)));
+            HIP_TRY(d_jobs.reserve(std::max<uint64_t>(jobs, 1)));
+            HIP_TRY(d_align.reserve(std::max<uint64_t>(jobs, 1)));
+            DpPipeArgs c = a;
+            c.reqs = d_reqs.p + begin; c.n_reqs = nc; c.n_jobs = jobs;
+            c.strings = d_strings.p; c.jobs = d_jobs.p; c.align = d_align.p; c.ops = d_ops.p;
+            c.cons = d_cons.p; c.msa = d_msa.p + begin; c.lds_bytes = lds;
+            st = timed_launch(ctx, LRSC_K_LF, [&]() { return launch_dp_retrieve(ctx->fm, c, ctx->stream); });
+            if(st != LRSC_OK) return st;
+            if(jobs) {
+                DpAlignArgs al{};
+                al.codes = d_query_codes; al.strings = d_strings.p; al.jobs = d_jobs.p; al.n_jobs = (uint32_t)jobs;
+                al.band_width = 200; al.match_score = 1; al.gap_penalty = -1; al.mismatch_penalty = -8;   // LongReadOverlap.cpp:635-643
+                al.ops = d_ops.p; al.out = d_align.p; al.max_s1 = max1; al.max_s2 = max2; al.reqs = c.reqs;
+                al.trace_stride = (uint64_t)(max1 + 17) * kDpTraceStride;
+                const uint32_t nw = (uint32_t)std::min<uint64_t>(n_waves, jobs);
+                HIP_TRY(d_trace.reserve(al.trace_stride * nw));
+                al.trace = d_trace.p;
+                st = timed_launch(ctx, LRSC_K_DP, [&]() { return launch_dp_align(al, nw, ctx->stream); });
+                if(st != LRSC_OK) return st;
+            }
+            if(std::getenv("LRSC_DP_DEBUG")) {
+                std::vector<DpAlignOut> ao(jobs);
+                std::vector<DpJob> jj(jobs);
+                (void)hipMemcpy(ao.data(), d_align.p, jobs * sizeof(DpAlignOut), hipMemcpyDeviceToHost);
+                (void)hipMemcpy(jj.data(), d_jobs.p, jobs * sizeof(DpJob), hipMemcpyDeviceToHost);
+                for(uint32_t i = begin; i < end && i < begin + 3; ++i) {
+                    const DpRequest& r = reqs[i];
+                    std::fprintf(stderr, "[dp] req %u lq %u k %u cov %u cnt %u %u %u %u rows %llu %llu %llu %llu n_str %u max_len %u\n", i, r.lq, r.k,
+                                 r.coverage, r.cnt[0], r.cnt[1], r.cnt[2], r.cnt[3], (unsigned long long)r.row_lo[0], (unsigned long long)r.row_lo[1],
+                                 (unsigned long long)r.row_lo[2], (unsigned long long)r.row_lo[3], r.n_str, r.max_len);
+                    for(uint32_t s = 0; s < r.n_str; ++s) {
+                        const DpAlignOut& o = ao[r.job_first + s];
+                        std::fprintf(stderr, "[dp]   str %u len %u mode %u skipped %u accept %u cols %d edit %d m0 %d-%d m1 %d-%d nops %u\n", s,
+                                     jj[r.job_first + s].s2_len, jj[r.job_first + s].mode, o.skipped, o.accept, o.total_columns, o.edit_distance,
+                                     o.m0s, o.m0e, o.m1s, o.m1e, o.n_ops);
+                    }
+                }
+            }
+            st = timed_launch(ctx, LRSC_K_MSA, [&]() { return launch_dp_msa(c, ctx->stream); });
+            if(st != LRSC_OK) return st;
+            n_strings += jobs;
+            begin = end;
+        }
+        return LRSC_OK;
+    }
+};
+
+extern "C" int lrsc_dp_consensus(lrsc_ctx* ctx, const char* seq, uint64_t seq_len, const lrsc_msa_query* queries, uint32_t n,
+                                 lrsc_msa_result* results, char* arena, uint64_t arena_cap, uint64_t* arena_used)
+{
+    if(!ctx || (!queries && n) || (!results && n) || !arena_used || (!seq && seq_len)) return fail(LRSC_ERR_ARG, "null");
+    *arena_used = 0;
+    if(n == 0) return LRSC_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<uint8_t> codes;
+    int st = encode_acgt(seq, seq_len, codes);
+    if(st != LRSC_OK) return st;
+    std::vector<DpRequest> reqs(n);
+    for(uint32_t i = 0; i < n; ++i) {
+        const lrsc_msa_query& q = queries[i];
+        if(q.seq_off + q.len > seq_len) return fail(LRSC_ERR_ARG, "msa query out of range");
+        DpRequest& r = reqs[i];
+        std::memset(&r, 0, sizeof(r));
+        r.q_off = q.seq_off; r.lq = q.len; r.k = q.kmer_len; r.min_overlap = q.min_overlap; r.min_call_coverage = q.min_call_coverage;
+        r.min_identity = q.min_identity; r.coverage = (uint32_t)ctx->params.pb_coverage;
+    }
+    DevBuf<uint8_t> d_codes;
+    HIP_TRY(d_codes.reserve(std::max<uint64_t>(seq_len, 1)));
+    HIP_TRY(hipMemcpyAsync(d_codes.p, codes.data(), seq_len, hipMemcpyHostToDevice, ctx->stream));
+    DpStage stage;
+    st = stage.run(ctx, d_codes.p, reqs);
+    if(st != LRSC_OK) return st;
+    std::vector<DpMsaOut> mo(n);
+    std::vector<uint8_t> cons(stage.cons_total);
+    HIP_TRY(hipMemcpy(mo.data(), stage.d_msa.p, (size_t)n * sizeof(DpMsaOut), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(cons.data(), stage.d_cons.p, stage.cons_total, hipMemcpyDeviceToHost));
+    uint64_t used = 0;
+    for(uint32_t i = 0; i < n; ++i) {
+        if(mo[i].error) return fail(LRSC_ERR_CAPACITY, "msa: column capacity exceeded");
+        results[i].n_rows = mo[i].n_rows; results[i].n_retrieved = reqs[i].n_str; results[i].cons_len = mo[i].cons_len; results[i].pad = 0;
+        results[i].cons_off = used;
+        if(arena && used + mo[i].cons_len <= arena_cap)
+            for(uint32_t t = 0; t < mo[i].cons_len; ++t) arena[used + t] = "ACGT"[cons[reqs[i].cons_off + t] & 3u];
+        used += mo[i].cons_len;
+    }
+    *arena_used = used;
+    if(used > arena_cap || (!arena && used)) return fail(LRSC_ERR_CAPACITY, "consensus arena too small");
     return LRSC_OK;
 }

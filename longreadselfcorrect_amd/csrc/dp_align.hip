@@ -51,15 +51,26 @@ __global__ __launch_bounds__(64) void dp_align_kernel(DpAlignArgs a)
         const DpJob J = a.jobs[job];
         DpAlignOut o;
         o.m0s = 0; o.m0e = -1; o.m1s = 0; o.m1e = -1; o.score = -1; o.edit_distance = -1; o.total_columns = -1; o.n_ops = 0;
-        if(J.skip || J.s1_len == 0 || J.s2_len == 0) {
+        o.accept = 0; o.skipped = 1;
+        if(J.s1_len == 0 || J.s2_len == 0) {
             if(lane == 0) a.out[job] = o;
             continue;
         }
         const int L1 = (int)J.s1_len, L2 = (int)J.s2_len;
         __syncthreads();
         for(int i = (int)lane; i <= L1; i += 64) S1[i] = i < L1 ? a.codes[J.s1_off + i] : (uint8_t)4;
-        for(int j = (int)lane; j <= L2 + 4; j += 64) S2[j] = j < L2 ? a.codes[J.s2_off + j] : (uint8_t)4;
+        for(int j = (int)lane; j <= L2 + 4; j += 64) S2[j] = j < L2 ? a.strings[J.s2_off + j] : (uint8_t)4;
         __syncthreads();
+        if(J.mode != 0 && L2 >= L1) {                              // identical sequence from the forward / backward extension
+            const int shift = J.mode == 1 ? 0 : L2 - L1;
+            bool diff = false;
+            for(int i = (int)lane; i < L1; i += 64) diff = diff || S1[i] != S2[shift + i];
+            if(__ballot(diff) == 0) {
+                if(lane == 0) a.out[job] = o;
+                continue;
+            }
+        }
+        o.skipped = 0;
 
         const int origin = (J.start2 - J.start1 + 1) - (half + 1);
         const int num_rows = L2 + 1;
@@ -195,6 +206,12 @@ __global__ __launch_bounds__(64) void dp_align_kernel(DpAlignArgs a)
         if((n_ops & 63u) != 0 && lane < (n_ops & 63u)) ops[(n_ops & ~63u) + lane] = (uint8_t)acc;
         o.m0s = ti; o.m1s = tj;
         o.n_ops = bad ? 0xFFFFFFFFu : n_ops;
+        if(a.reqs && !bad) {
+            const DpRequest& R = a.reqs[J.req];
+            const bool bPassedOverlap = (uint64_t)(int64_t)o.total_columns >= (uint64_t)R.min_overlap;
+            const double pid = (double)(o.total_columns - o.edit_distance) * 100.0f / o.total_columns;      // getPercentIdentity
+            o.accept = (bPassedOverlap && pid / 100 >= R.min_identity) ? 1u : 0u;
+        }
         if(lane == 0) a.out[job] = o;
     }
 }

@@ -1,0 +1,237 @@
+// dp_msa.hip -- MultipleAlignment::addOverlap / _addSequence / calculateBaseConsensus
+// (Thirdparty/multiple_alignment.cpp:208-393,517-594, as driven by LongReadOverlap::buildMultipleAlignment,
+// PacBio/LongReadOverlap.cpp:17-55) on the device: one WAVEFRONT per correctByMSAlignment call, state in LDS.
+//
+// The reference keeps every row's padded string; the consensus only needs, per column, how many rows show
+// A / C / G / T / '-', plus the padded base row.  So the state here is
+//   T[]            the base row's padded_sequence (codes 0-3, kGap),
+//   cnt[col]       five 16-bit counters per global column,
+//   lead[e],size[e] leading_columns and padded length of every other row (what insertGapBeforeColumn looks at),
+// and the operations are the reference's, step for step, including its quirks: incoming rows are aligned against
+// the base row only; an insertion opens a new column unless the base row already has a gap column *at the
+// current template position*; leading_columns of the base row is read once per incoming row (:306), so an
+// insertion in front of base 0 moves the template cursor past a base without consuming a cigar op.
+// Rows are added in retrieval order (source-seed strings, then target-seed strings).
+#include <hip/hip_runtime.h>
+
+#include "dp_dev.h"
+
+namespace lrsc {
+
+namespace {
+constexpr uint32_t kGap = 4;
+struct Cnt { uint16_t c[6]; };             // A C G T '-' (pad)
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ uint32_t mbcnt(uint64_t mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+} // namespace
+
+uint32_t dp_msa_lds_bytes(uint32_t lq, uint32_t str_cap, uint32_t ops_cap, uint32_t coverage)
+{
+    const uint32_t W = dp_msa_columns(lq), E = 4 * coverage + 4;
+    uint32_t o = 0;
+    o += W * (uint32_t)sizeof(Cnt);        // cnt
+    o += E * 8;                            // lead, size
+    o += (W + 3) & ~3u;                    // T
+    o += (W + 3) & ~3u;                    // outsym
+    o += (str_cap + 3) & ~3u;              // S
+    o += (ops_cap + 3) & ~3u;              // ops
+    return o;
+}
+
+__global__ __launch_bounds__(64) void dp_msa_kernel(DpPipeArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t lane = lane_id();
+    for(uint32_t rq = blockIdx.x; rq < a.n_reqs; rq += gridDim.x) {
+        const DpRequest R = a.reqs[rq];
+        const uint32_t W = dp_msa_columns(R.lq), E = 4 * R.coverage + 4;
+        Cnt* cnt = reinterpret_cast<Cnt*>(smem);
+        uint32_t* lead = reinterpret_cast<uint32_t*>(smem + W * sizeof(Cnt));
+        uint32_t* size = lead + E;
+        uint8_t* T = reinterpret_cast<uint8_t*>(size + E);
+        uint8_t* outsym = T + ((W + 3) & ~3u);
+        uint8_t* S = outsym + ((W + 3) & ~3u);
+        uint8_t* ops = S + ((R.str_cap + 3) & ~3u);
+        __syncthreads();
+        const uint8_t* q = a.codes + R.q_off;
+        for(uint32_t c = lane; c < W; c += 64) {
+            Cnt z; z.c[0] = z.c[1] = z.c[2] = z.c[3] = z.c[4] = z.c[5] = 0;
+            if(c < R.lq) { T[c] = q[c]; z.c[q[c]] = 1; }
+            cnt[c] = z;
+        }
+        __syncthreads();
+        uint32_t lead_b = 0, size_b = R.lq, n_el = 0, n_rows = 1;
+        bool overflow = false;
+
+        for(uint32_t s = 0; s < R.n_str && !overflow; ++s) {
+            const DpAlignOut A = a.align[R.job_first + s];
+            if(!A.accept) continue;
+            const DpJob J = a.jobs[R.job_first + s];
+            ++n_rows;
+            __syncthreads();
+            for(uint32_t i = lane; i < J.s2_len; i += 64) S[i] = a.strings[J.s2_off + i];
+            for(uint32_t i = lane; i < A.n_ops; i += 64) ops[i] = a.ops[J.ops_off + A.n_ops - 1 - i];      // forward order
+            __syncthreads();
+
+            // getPaddedPositionOfBase(match[0].start): index in T of the match0_start-th non-gap symbol
+            uint32_t ti = 0;
+            {
+                uint32_t seen = 0;
+                const uint32_t want = (uint32_t)A.m0s;
+                for(uint32_t base = 0; base < size_b; base += 64) {
+                    const uint32_t i = base + lane;
+                    const bool ng = i < size_b && T[i] != kGap;
+                    const uint64_t m = __ballot(ng);
+                    const uint32_t nn = (uint32_t)__builtin_popcountll(m);
+                    if(seen + nn > want) {
+                        const uint64_t hit = __ballot(ng && mbcnt(m) == want - seen);
+                        ti = base + (uint32_t)__builtin_ctzll(hit);
+                        break;
+                    }
+                    seen += nn;
+                }
+            }
+            const uint32_t tl = lead_b;                         // template_leading, read once (:306)
+            const uint32_t il = ti + tl;                        // incoming_leading
+            uint32_t inc = (uint32_t)A.m1s, cig = 0, nout = 0;
+            while(cig < A.n_ops) {
+                const uint32_t tsym = ti < size_b ? T[ti] : 0xFFu;          // past the end: the string's NUL, not a gap
+                const uint32_t op = ops[cig];
+                uint32_t sym;
+                if(tsym == kGap) {
+                    if(op == 'I') { sym = S[inc++]; ++cig; }
+                    else sym = kGap;
+                } else if(op == 'M') { sym = S[inc++]; ++cig; }
+                else if(op == 'D') { sym = kGap; ++cig; }
+                else {
+                    // insertGapBeforeColumn(template_index + template_leading) on every row (:1205-1211, :165-180)
+                    const uint32_t c = ti + tl;
+                    uint32_t ngap = 0;
+                    for(uint32_t e0 = 0; e0 < n_el; e0 += 64) {
+                        const uint32_t e = e0 + lane;
+                        bool inside = false;
+                        if(e < n_el) {
+                            const uint32_t le = lead[e], se = size[e];
+                            if(c <= le) lead[e] = le + 1;
+                            else if(c - le < se) { size[e] = se + 1; inside = true; }
+                        }
+                        ngap += (uint32_t)__builtin_popcountll(__ballot(inside));
+                    }
+                    const uint32_t end_b = lead_b + size_b;                  // tracked columns: [0, end_b)
+                    bool base_inside = false;
+                    if(c <= lead_b) lead_b += 1;
+                    else if(c - lead_b < size_b) {
+                        base_inside = true;
+                        const uint32_t ip = c - lead_b;
+                        if(size_b + 1 > W) { overflow = true; break; }
+                        for(uint32_t hi = size_b; hi > ip;) {                // T.insert(ip, '-')
+                            const uint32_t n = hi - ip < 64 ? hi - ip : 64;
+                            const uint32_t i = hi - 1 - lane;
+                            uint8_t v = 0;
+                            if(lane < n) v = T[i];
+                            __syncthreads();
+                            if(lane < n) T[i + 1] = v;
+                            __syncthreads();
+                            hi -= n;
+                        }
+                        if(lane == 0) T[ip] = (uint8_t)kGap;
+                        size_b += 1;
+                    }
+                    if(c < end_b) {                                          // columns at / after c move right
+                        if(end_b + 1 > W) { overflow = true; break; }
+                        for(uint32_t hi = end_b; hi > c;) {
+                            const uint32_t n = hi - c < 64 ? hi - c : 64;
+                            const uint32_t i = hi - 1 - lane;
+                            Cnt v;
+                            if(lane < n) v = cnt[i];
+                            __syncthreads();
+                            if(lane < n) cnt[i + 1] = v;
+                            __syncthreads();
+                            hi -= n;
+                        }
+                    }
+                    if(c < W && lane == 0) {
+                        Cnt z; z.c[0] = z.c[1] = z.c[2] = z.c[3] = z.c[5] = 0;
+                        z.c[4] = (uint16_t)(ngap + (base_inside ? 1u : 0u));
+                        cnt[c] = z;
+                    }
+                    __syncthreads();
+                    sym = S[inc++]; ++cig;
+                }
+                if(nout >= W) { overflow = true; break; }
+                if(lane == 0) outsym[nout] = (uint8_t)sym;
+                ++nout;
+                ++ti;
+            }
+            if(overflow) break;
+            __syncthreads();
+            if(n_el >= E) { overflow = true; break; }
+            if(lane == 0) { lead[n_el] = il; size[n_el] = nout; }
+            ++n_el;
+            for(uint32_t t = lane; t < nout; t += 64) {
+                const uint32_t col = il + t;
+                if(col < W) cnt[col].c[outsym[t]] += 1;
+            }
+            __syncthreads();
+        }
+
+        // calculateBaseConsensus(min_call_coverage, -1) over the base row's columns
+        uint32_t cons_len = 0;
+        uint8_t* cons = a.cons + R.cons_off;
+        if(!overflow) {
+            for(uint32_t base = 0; base < size_b; base += 64) {
+                const uint32_t i = base + lane;
+                uint32_t sym = kGap;
+                if(i < size_b && lead_b + i < W) {
+                    const Cnt v = cnt[lead_b + i];
+                    int max_count = -1; uint32_t max_symbol = 0;
+#pragma unroll
+                    for(uint32_t x = 0; x < 5; ++x)                         // "ACGT" then '-' ('N' never counted)
+                        if((int)v.c[x] > max_count) { max_count = (int)v.c[x]; max_symbol = x; }
+                    const uint32_t base_symbol = T[i];
+                    const int base_count = (int)v.c[base_symbol];
+                    sym = (max_count >= base_count && base_count < R.min_call_coverage) ? max_symbol : base_symbol;
+                }
+                const bool keep = i < size_b && sym != kGap;
+                const uint64_t m = __ballot(keep);
+                if(keep) {
+                    const uint32_t pos = cons_len + mbcnt(m);
+                    if(pos < R.cons_cap) cons[pos] = (uint8_t)sym;
+                }
+                cons_len += (uint32_t)__builtin_popcountll(m);
+            }
+            if(cons_len > R.cons_cap) overflow = true;
+        }
+        if(lane == 0) {
+            DpMsaOut o;
+            o.n_rows = n_rows; o.cons_len = overflow ? 0 : cons_len; o.error = overflow ? 1u : 0u; o.pad = 0;
+            a.msa[rq] = o;
+        }
+    }
+}
+
+hipError_t launch_dp_msa(const DpPipeArgs& a, hipStream_t stream)
+{
+    if(a.n_reqs == 0) return hipSuccess;
+    if(a.lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+    if(a.lds_bytes > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dp_msa_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)a.lds_bytes);
+        if(e != hipSuccess) return e;
+    }
+    int cus = 256, dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    uint32_t per_cu = a.lds_bytes ? (160u * 1024u) / a.lds_bytes : 16u;
+    per_cu = per_cu < 1 ? 1 : per_cu > 16 ? 16 : per_cu;
+    uint32_t n_waves = (uint32_t)cus * per_cu;
+    if(n_waves > a.n_reqs) n_waves = a.n_reqs;
+    hipLaunchKernelGGL(dp_msa_kernel, dim3(n_waves), dim3(64), a.lds_bytes, stream, a);
+    return hipGetLastError();
+}
+
+} // namespace lrsc

@@ -255,6 +255,31 @@ int orc_extend_walk(void* bwt, void* rbwt, const lrsc_params* p, const char* src
     return code;
 }
 
+// ---- DP/MSA fallback: buildMultipleAlignment + calculateBaseConsensus -------------------------------------------
+// Returns the number of rows of the alignment; consensus (NUL-terminated) into out; n3 = {retrieved strings fwd-seed,
+// retrieved strings RC-seed, consensus length}.
+int orc_dp_consensus(void* bwt, void* rbwt, const char* query, int k, int min_overlap, double min_identity, int coverage,
+                     int min_call_coverage, char* out, int out_cap, int* n3)
+{
+    IndexSet idx;
+    idx.bwt = static_cast<RLBwt*>(bwt);
+    idx.rbwt = static_cast<RLBwt*>(rbwt);
+    const std::string q(query);
+    if(n3) {
+        std::vector<std::string> a, b;
+        const size_t maxLength = q.length() * 1.1 + 20;
+        retrieveStr(q, (size_t)k, maxLength, idx, false, (size_t)coverage, a);
+        retrieveStr(q, (size_t)k, maxLength, idx, true, (size_t)coverage, b);
+        n3[0] = (int)a.size(); n3[1] = (int)b.size();
+    }
+    MultipleAlignment ma = buildMultipleAlignment(q, (size_t)k, (size_t)k, (size_t)min_overlap, min_identity, (size_t)coverage, idx);
+    const std::string cons = ma.calculateBaseConsensus(min_call_coverage, -1);
+    if(n3) n3[2] = (int)cons.size();
+    if((int)cons.size() + 1 > out_cap) return -100;
+    std::memcpy(out, cons.c_str(), cons.size() + 1);
+    return (int)ma.getNumRows();
+}
+
 // ---- the whole per-read path (PacBioSelfCorrectionProcess::process + PostProcess) ---------------------------
 struct OrcRun {
     std::string correct_fa, discard_fa, stats;

@@ -94,6 +94,9 @@ class Oracle:
         L.orc_itree_query.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64]
         L.orc_extend_match.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_void_p, C.c_char_p, C.c_int]
+        L.orc_dp_consensus.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_char_p,
+                                       C.c_int, C.c_void_p]
+        L.orc_dp_consensus.restype = C.c_int
         L.orc_extend_walk.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int,
                                       C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_void_p]
         L.orc_correct_reads.restype = C.c_void_p
@@ -115,6 +118,15 @@ class Oracle:
     def extend_match(self, s1: str, s2: str, start1: int, start2: int, bandwidth: int = 200, scores=(1, -1, -8)):
         self._decl_late()
         return _extend_match(self.lib.orc_extend_match, s1, s2, start1, start2, bandwidth, scores)
+
+    def dp_consensus(self, bwt, rbwt, query: str, k: int, min_overlap: int, min_identity: float, coverage: int, min_call_coverage: int):
+        """buildMultipleAlignment + calculateBaseConsensus -> (rows, consensus, retrieved strings)."""
+        out = C.create_string_buffer(4 * len(query) + 1024)
+        n3 = np.zeros(3, dtype=np.int32)
+        rows = self.lib.orc_dp_consensus(bwt.h, rbwt.h, query.encode(), k, min_overlap, min_identity, coverage, min_call_coverage, out,
+                                         len(out), _p(n3))
+        assert rows >= 0
+        return rows, out.value.decode(), int(n3[0] + n3[1])
 
     def extend_walk(self, bwt, rbwt, params, src: str, path: str, trg: str, dis: int, initk: int, max_overlap: int,
                     min_sa: int):

@@ -473,3 +473,41 @@ def test_dp_align_matches_oracle_extend_match(gpu_ctx, oracle, small_ds):
         got = gpu_ctx.dp_align(sub, band_width=bw, scores=(2, -3, -5))
         for (s1, s2, a, b), g in zip(sub, got):
             assert g == oracle.extend_match(s1, s2, a, b, bandwidth=bw, scores=(2, -3, -5)), (bw, s1, s2, a, b)
+
+
+def _dp_queries(rng, ds, n):
+    """(query, k, min_overlap, min_identity, min_call_coverage) the way correctByMSAlignment builds them
+    (PacBioSelfCorrectionProcess.cpp:208-236): query = a read substring (source k-mer + gap + target seed)."""
+    out = []
+    for t in range(n):
+        r = int(rng.integers(len(ds.reads)))
+        read = ds.reads[r]
+        L = int(rng.integers(60, 400))
+        if len(read) < L + 2:
+            continue
+        p = int(rng.integers(0, len(read) - L))
+        q = read[p: p + L]
+        k = int(rng.choice([13, 15, 17, 19]))
+        ident = [0.65, 0.65 + 0.05, 0.65 + 0.05 + 0.05][t % 3]
+        out.append((q, k, len(q) // 10, ident, [15, 15, 24, 40][t % 4]))
+    return out
+
+
+@pytest.mark.parametrize("cov", [90, 20])
+def test_dp_consensus_matches_oracle(api, gpu_index, oracle, small_ds, cov):
+    """retrieveStr + extendMatch + MultipleAlignment + calculateBaseConsensus: rows, retrieved-string count and the
+    consensus string, bit-identical to the oracle's line-by-line restatement of LongReadOverlap.cpp / multiple_alignment.cpp."""
+    rng = np.random.default_rng(1234 + cov)
+    qs = _dp_queries(rng, small_ds, 60)
+    p = api.params_default(5, cov)
+    ctx = gpu_index.ctx(p, 0)
+    got = ctx.dp_consensus(qs)
+    ctx.close()
+    ob, orb = oracle.bwt_load(small_ds.prefix + ".bwt"), oracle.bwt_load(small_ds.prefix + ".rbwt")
+    n_multi = 0
+    for (q, k, mo, mi, mc), g in zip(qs, got):
+        want = oracle.dp_consensus(ob, orb, q, k, mo, mi, cov, mc)
+        assert g == want, (q, k, mo, mi, mc)
+        n_multi += want[0] > 3
+    assert n_multi >= 10                                   # real pile-ups, not only "too few rows"
+    ob.close(); orb.close()
