@@ -43,7 +43,8 @@ typedef enum lrsc_status {
     LRSC_ERR_NOMEM = -4,
     LRSC_ERR_DEVICE = -5,      /* HIP runtime error, no device, not uploaded     */
     LRSC_ERR_CAPACITY = -6,    /* caller-provided output buffer too small        */
-    LRSC_ERR_UNSUPPORTED = -7
+    LRSC_ERR_UNSUPPORTED = -7,
+    LRSC_ERR_LIMIT = -8           /* an internal capacity of the device implementation was exceeded (see lrsc_last_error) */
 } lrsc_status;
 
 typedef struct lrsc_index lrsc_index;   /* both strands' FM-index: host image + per-device copies */

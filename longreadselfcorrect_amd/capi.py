@@ -459,7 +459,7 @@ class Ctx:
             out = np.zeros(ocap, dtype=np.uint8)
             st = self.api.lib.lrsc_correct_reads(self.h, _ptr(bases), _ptr(off), n, res, _ptr(poff), pcap + 1, _ptr(out), ocap,
                                                  C.byref(npieces), C.byref(used))
-            if st == -6:
+            if st == -6 and (int(npieces.value) + 1 > pcap or int(used.value) > ocap):
                 pcap, ocap = max(pcap, int(npieces.value) + 1), max(ocap, int(used.value))
                 continue
             self.api.check(st, "lrsc_correct_reads")

@@ -143,6 +143,7 @@ extern "C" const char* lrsc_strerror(int status)
         case LRSC_ERR_DEVICE: return "HIP device error";
         case LRSC_ERR_CAPACITY: return "output buffer too small";
         case LRSC_ERR_UNSUPPORTED: return "unsupported";
+        case LRSC_ERR_LIMIT: return "internal capacity exceeded";
         default: return "unknown error";
     }
 }
@@ -1049,7 +1050,7 @@ extern "C" int lrsc_extend_walks(lrsc_ctx* ctx, const char* seq, uint64_t seq_le
     HIP_TRY(hipMemcpy(outp.data(), d_outp.p, out_total, hipMemcpyDeviceToHost));
     uint64_t used = 0;
     for(uint32_t w = 0; w < n; ++w) {
-        if(out[w].code <= LRSC_WALK_ERR_CHILDREN) return fail(LRSC_ERR_CAPACITY, "walk: internal frontier/result capacity exceeded");
+        if(out[w].code <= LRSC_WALK_ERR_CHILDREN) return fail(LRSC_ERR_LIMIT, "walk: internal frontier/result capacity exceeded");
         results[w].code = out[w].code; results[w].steps = out[w].steps; results[w].out_off = used; results[w].out_len = 0; results[w].pad = 0;
         if(out[w].code > 0) {
             const lrsc_walk_desc& d = walks[w];
@@ -1072,6 +1073,160 @@ extern "C" int lrsc_extend_walks(lrsc_ctx* ctx, const char* seq, uint64_t seq_le
     return LRSC_OK;
 }
 
+static int encode_acgt(const char* seq, uint64_t n, std::vector<uint8_t>& codes)
+{
+    codes.resize(n);
+    for(uint64_t i = 0; i < n; ++i) {
+        switch(seq[i]) {
+            case 'A': codes[i] = 0; break; case 'C': codes[i] = 1; break; case 'G': codes[i] = 2; break; case 'T': codes[i] = 3; break;
+            default: return fail(LRSC_ERR_ARG, "sequence contains a base other than A,C,G,T");
+        }
+    }
+    return LRSC_OK;
+}
+
+static uint32_t dp_wave_count(const lrsc_ctx* ctx)
+{
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    return (uint32_t)cus * 8u;
+}
+
+// The DP stage for a set of requests whose queries are already on the device: seeds -> (chunked by memory)
+// retrieve -> align -> MSA.  Results stay on the device (d_msa[i], consensus codes at d_cons + reqs[i].cons_off).
+struct DpStage {
+    DevBuf<DpRequest> d_reqs;
+    DevBuf<DpMsaOut> d_msa;
+    DevBuf<uint8_t> d_cons, d_strings, d_ops, d_trace;
+    DevBuf<DpJob> d_jobs;
+    DevBuf<DpAlignOut> d_align;
+    uint64_t cons_total = 0, n_strings = 0;
+
+    int run(lrsc_ctx* ctx, const uint8_t* d_query_codes, std::vector<DpRequest>& reqs)
+    {
+        const uint32_t n = (uint32_t)reqs.size();
+        n_strings = 0; cons_total = 0;
+        if(n == 0) return LRSC_OK;
+        for(DpRequest& r : reqs) {
+            if(r.k == 0 || r.lq < r.k) return fail(LRSC_ERR_ARG, "dp request: kmer_len must satisfy 1 <= kmer_len <= query length");
+            r.max_len = (uint32_t)(size_t)(r.lq * 1.1 + 20);                 // LongReadOverlap.cpp:618
+            r.str_cap = (std::max(r.max_len, r.k) + 3) & ~3u;
+            r.ops_cap = (r.lq + r.str_cap + 1 + 3) & ~3u;
+            r.cons_cap = dp_msa_columns(r.lq);
+            r.w_cols = dp_msa_columns(r.lq);
+            r.cons_off = cons_total;
+            cons_total += r.cons_cap;
+            if(((r.lq + 2 + 3) & ~3u) + r.str_cap + 8 > 64 * 1024) return fail(LRSC_ERR_UNSUPPORTED, "dp request: query longer than ~30 kb");
+            if(dp_msa_lds_bytes(r.w_cols, r.str_cap, r.ops_cap, r.coverage) > 160 * 1024)
+                return fail(LRSC_ERR_UNSUPPORTED, "dp request: query too long for the LDS-resident multiple alignment (~5 kb)");
+        }
+        HIP_TRY(d_reqs.reserve(n));
+        HIP_TRY(d_msa.reserve(n));
+        HIP_TRY(d_cons.reserve(cons_total));
+        HIP_TRY(hipMemcpyAsync(d_reqs.p, reqs.data(), (size_t)n * sizeof(DpRequest), hipMemcpyHostToDevice, ctx->stream));
+        DpPipeArgs a{};
+        a.codes = d_query_codes; a.reqs = d_reqs.p; a.n_reqs = n; a.ctr = ctx->d_ctr;
+        int st = timed_launch(ctx, LRSC_K_LF, [&]() { return launch_dp_seeds(ctx->fm, a, ctx->stream); });
+        if(st != LRSC_OK) return st;
+        HIP_TRY(hipMemcpy(reqs.data(), d_reqs.p, (size_t)n * sizeof(DpRequest), hipMemcpyDeviceToHost));
+
+        uint64_t budget = 16ull << 30;
+        if(const char* e = std::getenv("LRSC_DP_CHUNK_MB")) budget = std::max<uint64_t>(1, (uint64_t)std::atoll(e)) << 20;
+        const uint32_t n_waves = dp_wave_count(ctx);
+        uint32_t begin = 0;
+        while(begin < n) {
+            uint32_t end = begin, max1 = 1, max2 = 1, lds = 0;
+            uint64_t jobs = 0, sbytes = 0, obytes = 0;
+            while(end < n) {
+                DpRequest& r = reqs[end];
+                r.n_str = r.cnt[0] + r.cnt[1] + r.cnt[2] + r.cnt[3];
+                const uint64_t sb = (uint64_t)r.n_str * r.str_cap, ob = (uint64_t)r.n_str * r.ops_cap;
+                if(end > begin && sbytes + obytes + sb + ob + (jobs + r.n_str) * (sizeof(DpJob) + sizeof(DpAlignOut)) > budget) break;
+                r.job_first = jobs; r.str_off = sbytes; r.ops_off = obytes;
+                jobs += r.n_str; sbytes += sb; obytes += ob;
+                max1 = std::max(max1, r.lq); max2 = std::max(max2, r.str_cap);
+                lds = std::max(lds, dp_msa_lds_bytes(r.w_cols, r.str_cap, r.ops_cap, r.coverage));
+                ++end;
+            }
+            if(jobs >= (1ull << 32)) return fail(LRSC_ERR_UNSUPPORTED, "dp chunk: too many alignments");
+            const uint32_t nc = end - begin;
+            HIP_TRY(hipMemcpyAsync(d_reqs.p + begin, reqs.data() + begin, (size_t)nc * sizeof(DpRequest), hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(d_strings.reserve(std::max<uint64_t>(sbytes, 64)));
+            HIP_TRY(d_ops.reserve(std::max<uint64_t>(obytes, 64)));
+            HIP_TRY(d_jobs.reserve(std::max<uint64_t>(jobs, 1)));
+            HIP_TRY(d_align.reserve(std::max<uint64_t>(jobs, 1)));
+            DpPipeArgs c = a;
+            c.reqs = d_reqs.p + begin; c.n_reqs = nc; c.n_jobs = jobs;
+            c.strings = d_strings.p; c.jobs = d_jobs.p; c.align = d_align.p; c.ops = d_ops.p;
+            c.cons = d_cons.p; c.msa = d_msa.p + begin; c.lds_bytes = lds;
+            st = timed_launch(ctx, LRSC_K_LF, [&]() { return launch_dp_retrieve(ctx->fm, c, ctx->stream); });
+            if(st != LRSC_OK) return st;
+            if(jobs) {
+                DpAlignArgs al{};
+                al.codes = d_query_codes; al.strings = d_strings.p; al.jobs = d_jobs.p; al.n_jobs = (uint32_t)jobs;
+                al.band_width = 200; al.match_score = 1; al.gap_penalty = -1; al.mismatch_penalty = -8;   // LongReadOverlap.cpp:635-643
+                al.ops = d_ops.p; al.out = d_align.p; al.max_s1 = max1; al.max_s2 = max2; al.reqs = c.reqs;
+                al.trace_stride = (uint64_t)(max1 + 17) * kDpTraceStride;
+                const uint32_t nw = (uint32_t)std::min<uint64_t>(n_waves, jobs);
+                HIP_TRY(d_trace.reserve(al.trace_stride * nw));
+                al.trace = d_trace.p;
+                st = timed_launch(ctx, LRSC_K_DP, [&]() { return launch_dp_align(al, nw, ctx->stream); });
+                if(st != LRSC_OK) return st;
+            }
+            if(std::getenv("LRSC_DP_DEBUG")) {
+                std::vector<DpAlignOut> ao(jobs);
+                std::vector<DpJob> jj(jobs);
+                (void)hipMemcpy(ao.data(), d_align.p, jobs * sizeof(DpAlignOut), hipMemcpyDeviceToHost);
+                (void)hipMemcpy(jj.data(), d_jobs.p, jobs * sizeof(DpJob), hipMemcpyDeviceToHost);
+                for(uint32_t i = begin; i < end && i < begin + 3; ++i) {
+                    const DpRequest& r = reqs[i];
+                    std::fprintf(stderr, "[dp] req %u lq %u k %u cov %u cnt %u %u %u %u rows %llu %llu %llu %llu n_str %u max_len %u\n", i, r.lq, r.k,
+                                 r.coverage, r.cnt[0], r.cnt[1], r.cnt[2], r.cnt[3], (unsigned long long)r.row_lo[0], (unsigned long long)r.row_lo[1],
+                                 (unsigned long long)r.row_lo[2], (unsigned long long)r.row_lo[3], r.n_str, r.max_len);
+                    for(uint32_t s = 0; s < r.n_str; ++s) {
+                        const DpAlignOut& o = ao[r.job_first + s];
+                        std::fprintf(stderr, "[dp]   str %u len %u mode %u skipped %u accept %u cols %d edit %d m0 %d-%d m1 %d-%d nops %u\n", s,
+                                     jj[r.job_first + s].s2_len, jj[r.job_first + s].mode, o.skipped, o.accept, o.total_columns, o.edit_distance,
+                                     o.m0s, o.m0e, o.m1s, o.m1e, o.n_ops);
+                    }
+                }
+            }
+            st = timed_launch(ctx, LRSC_K_MSA, [&]() { return launch_dp_msa(c, ctx->stream); });
+            if(st != LRSC_OK) return st;
+            // a pile-up that opened more gap columns than its capacity is redone with twice the columns
+            std::vector<DpMsaOut> mo(nc);
+            std::vector<uint32_t> redo;
+            DevBuf<uint32_t> d_redo;
+            for(;;) {
+                HIP_TRY(hipMemcpy(mo.data(), d_msa.p + begin, (size_t)nc * sizeof(DpMsaOut), hipMemcpyDeviceToHost));
+                redo.clear();
+                uint32_t lds2 = 0;
+                for(uint32_t i = 0; i < nc; ++i) {
+                    if(mo[i].error == 2) return fail(LRSC_ERR_LIMIT, "msa: consensus longer than 2 x query + 128");
+                    if(mo[i].error != 1) continue;
+                    DpRequest& r = reqs[begin + i];
+                    r.w_cols *= 2;
+                    const uint32_t need = dp_msa_lds_bytes(r.w_cols, r.str_cap, r.ops_cap, r.coverage);
+                    if(need > 160 * 1024) return fail(LRSC_ERR_LIMIT, "msa: the multiple alignment of a DP fallback needs more columns than fit the 160 KB LDS");
+                    lds2 = std::max(lds2, need);
+                    redo.push_back(i);
+                }
+                if(redo.empty()) break;
+                HIP_TRY(d_redo.reserve(redo.size()));
+                HIP_TRY(hipMemcpyAsync(d_reqs.p + begin, reqs.data() + begin, (size_t)nc * sizeof(DpRequest), hipMemcpyHostToDevice, ctx->stream));
+                HIP_TRY(hipMemcpyAsync(d_redo.p, redo.data(), redo.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+                DpPipeArgs c2 = c;
+                c2.req_list = d_redo.p; c2.n_list = (uint32_t)redo.size(); c2.lds_bytes = lds2;
+                st = timed_launch(ctx, LRSC_K_MSA, [&]() { return launch_dp_msa(c2, ctx->stream); });
+                if(st != LRSC_OK) return st;
+            }
+            n_strings += jobs;
+            begin = end;
+        }
+        return LRSC_OK;
+    }
+};
+
 // ---------------------------------------------------------------------------------------
 // the whole per-read path on the device
 // ---------------------------------------------------------------------------------------
@@ -1084,7 +1239,6 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
     if(!ctx || !b || b->ctx != ctx || !res || !n_pieces_out || !out_used) return fail(LRSC_ERR_ARG, "null / foreign batch");
     *n_pieces_out = 0; *out_used = 0;
     const lrsc_params& p = ctx->params;
-    if(!p.no_dp) return fail(LRSC_ERR_UNSUPPORTED, "the DP/MSA fallback is not part of the product yet: set no_dp");
     if(p.max_leaves < 1 || p.max_leaves > 32) return fail(LRSC_ERR_UNSUPPORTED, "max_leaves must be 1..32");
     if(p.idmer_len < 5 || p.idmer_len > 16) return fail(LRSC_ERR_UNSUPPORTED, "idmer_len must be 5..16");
     if(p.min_kmer_len < p.idmer_len || p.min_kmer_len > 62) return fail(LRSC_ERR_UNSUPPORTED, "min_kmer_len out of range");
@@ -1125,7 +1279,7 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
     a.n_reads = n; a.min_k = b->min_k;
     a.plan = d_plan.p; a.out = d_out.p; a.work = d_work.p; a.order = d_order.p;
     a.seed_size = (uint32_t)p.idmer_len; a.min_overlap = (uint32_t)p.min_kmer_len; a.max_leaves = (uint32_t)p.max_leaves;
-    a.start_kmer_len = p.start_kmer_len; a.next_target = p.next_target; a.split = p.split;
+    a.start_kmer_len = p.start_kmer_len; a.next_target = p.next_target; a.split = p.split; a.no_dp = p.no_dp;
     a.pb_coverage = (uint64_t)p.pb_coverage; a.pacbio_error_rate = p.error_rate;
     a.freqs_of_kmer_size = d_freqs.p;
     a.ctr = ctx->d_ctr;
@@ -1154,7 +1308,8 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
         w.out_off = out_total; w.piece_off = piece_total; w.ws_off = ws_total;
         if(ns < 2) continue;                                          // nothing to correct: the read is discarded
         // every walk appends at most maxLength + 1 + |target| - initk characters, walks <= seeds, gaps sum to <= |read|
-        const uint64_t cap = rlen + (uint64_t)(1.2 * (double)rlen) + (uint64_t)ns * (2 * kMaxInitK + 16) + 64;
+        // (a DP consensus can be longer than its query by the insertion columns it keeps: budget 2x the raw segment)
+        const uint64_t cap = rlen + (uint64_t)((p.no_dp ? 1.2 : 2.0) * (double)rlen) + (uint64_t)ns * (2 * kMaxInitK + 16 + (p.no_dp ? 0 : 128)) + 64;
         if(cap >= (1ull << 32)) return fail(LRSC_ERR_UNSUPPORTED, "read too long");
         w.out_cap = (uint32_t)cap;
         w.piece_cap = p.split ? ns : 1;
@@ -1183,6 +1338,7 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
         w.o_next5 = (uint32_t)o;  o += (size_t)n5 * 2;
         w.o_flags5 = (uint32_t)o; o += n5;
         w.o_query = (uint32_t)o;  o += lq;
+        w.o_dpq = (uint32_t)o;    o += lq;
         o = align_up(o, 64);
         if(o >= (1ull << 32)) return fail(LRSC_ERR_UNSUPPORTED, "read workspace too large");
         ws_total += o;
@@ -1202,9 +1358,58 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
     int st = timed_launch(ctx, LRSC_K_EXTEND, [&]() { return launch_correct_reads(ctx->fm, a, ctx->stream); });
     if(st != LRSC_OK) return st;
 
-    // ---- results ---------------------------------------------------------------------------------------------
+    // ---- DP rounds: reads whose FM-extension failed are parked with a correctByMSAlignment request; the DP stage
+    //      answers all of them at once and the kernel resumes just those reads (:129-149) -------------------------------
     std::vector<ReadOut> ro(n);
     HIP_TRY(hipMemcpy(ro.data(), d_out.p, (size_t)n * sizeof(ReadOut), hipMemcpyDeviceToHost));
+    if(!p.no_dp) {
+        DpStage stage;
+        DevBuf<uint32_t> d_dp_index, d_parked;
+        std::vector<uint32_t> parked, dp_index(n, 0);
+        std::vector<DpRequest> reqs;
+        HIP_TRY(d_dp_index.reserve(n));
+        HIP_TRY(d_parked.reserve(n));
+        for(uint32_t round = 0;; ++round) {
+            parked.clear(); reqs.clear();
+            for(uint32_t i = 0; i < n; ++i) {
+                const uint32_t r = order[i];                    // keep the long-reads-first order
+                const ReadOut& o = ro[r];
+                if(o.error != 0 || o.state != kReadParked) continue;
+                DpRequest q;
+                std::memset(&q, 0, sizeof(q));
+                q.q_off = work[r].ws_off + work[r].o_dpq;
+                q.lq = o.dp_lq; q.k = o.dp_k;
+                q.coverage = (uint32_t)p.pb_coverage;
+                q.min_overlap = o.dp_lq / 10;                                            // path.length() / 10
+                // identity / min_call_coverage from the two seeds' maxFixedMerFreq (:225-229)
+                const size_t total = (size_t)o.dp_total_freq;
+                double identity = 0.65;
+                size_t min_call_coverage = 15;
+                identity += (total > 50 ? 0.05 : 0);
+                identity += (total > 100 ? 0.05 : 0);
+                min_call_coverage = total > 50 ? total * 0.4 : min_call_coverage;
+                q.min_identity = identity; q.min_call_coverage = (int32_t)min_call_coverage;
+                dp_index[r] = (uint32_t)reqs.size();
+                reqs.push_back(q);
+                parked.push_back(r);
+            }
+            if(parked.empty()) break;
+            st = stage.run(ctx, d_ws.p, reqs);
+            if(st != LRSC_OK) return st;
+            HIP_TRY(hipMemcpyAsync(d_dp_index.p, dp_index.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(d_parked.p, parked.data(), parked.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+            CorrectArgs b2 = a;
+            b2.resume = 1; b2.order = d_parked.p; b2.n_reads = (uint32_t)parked.size();
+            b2.dp_index = d_dp_index.p; b2.dp_reqs = stage.d_reqs.p; b2.dp_msa = stage.d_msa.p; b2.dp_cons = stage.d_cons.p;
+            st = timed_launch(ctx, LRSC_K_EXTEND, [&]() { return launch_correct_reads(ctx->fm, b2, ctx->stream); });
+            if(st != LRSC_OK) return st;
+            HIP_TRY(hipMemcpy(ro.data(), d_out.p, (size_t)n * sizeof(ReadOut), hipMemcpyDeviceToHost));
+            if(std::getenv("LRSC_CORRECT_PROFILE"))
+                std::fprintf(stderr, "[lrsc] DP round %u: %zu reads parked, %llu strings aligned\n", round, parked.size(),
+                             (unsigned long long)stage.n_strings);
+        }
+    }
+    a.n_reads = n;
     std::vector<uint32_t> pieces(std::max<uint64_t>(piece_total, 1));
     if(piece_total) HIP_TRY(hipMemcpy(pieces.data(), d_pieces.p, (size_t)piece_total * sizeof(uint32_t), hipMemcpyDeviceToHost));
     if(std::getenv("LRSC_CORRECT_PROFILE")) {
@@ -1220,7 +1425,9 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
         const ReadOut& o = ro[r];
         if(o.error == LRSC_WALK_ERR_GEOMETRY) return fail(LRSC_ERR_ARG, "correct: a walk's geometry is out of range (seed shorter than the extension k-mer, overlapping seeds, or init k-mer > 59)");
         if(o.error == LRSC_WALK_ERR_CODE) return fail(LRSC_ERR_UNSUPPORTED, "correct: FM-extension returned -4");
-        if(o.error != 0) return fail(LRSC_ERR_CAPACITY, "correct: internal frontier/result/output capacity exceeded");
+        if(o.error == LRSC_WALK_ERR_DP) return fail(LRSC_ERR_LIMIT, "correct: a DP consensus came back shorter than its k-mer or with an error");
+        if(o.error == LRSC_WALK_ERR_OUTPUT) return fail(LRSC_ERR_LIMIT, "correct: a corrected read outgrew its output slot");
+        if(o.error != 0) return fail(LRSC_ERR_LIMIT, "correct: walk frontier / result capacity exceeded");
         lrsc_read_result& R = res[r];
         R.merge = (int32_t)o.merge; R.n_pieces = o.n_pieces; R.piece_first = n_pieces;
         R.total_reads_len = o.c[0]; R.corrected_len = o.c[1]; R.total_seed_num = o.c[2]; R.total_walk_num = o.c[3];
@@ -1252,25 +1459,6 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
 // ---------------------------------------------------------------------------------------
 // DP/MSA fallback
 // ---------------------------------------------------------------------------------------
-static int encode_acgt(const char* seq, uint64_t n, std::vector<uint8_t>& codes)
-{
-    codes.resize(n);
-    for(uint64_t i = 0; i < n; ++i) {
-        switch(seq[i]) {
-            case 'A': codes[i] = 0; break; case 'C': codes[i] = 1; break; case 'G': codes[i] = 2; break; case 'T': codes[i] = 3; break;
-            default: return fail(LRSC_ERR_ARG, "sequence contains a base other than A,C,G,T");
-        }
-    }
-    return LRSC_OK;
-}
-
-static uint32_t dp_wave_count(const lrsc_ctx* ctx)
-{
-    int cus = 256;
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
-    return (uint32_t)cus * 8u;
-}
-
 extern "C" int lrsc_dp_align(lrsc_ctx* ctx, const char* seq, uint64_t seq_len, const lrsc_dp_job* jobs, uint32_t n, int band_width,
                              int match_score, int gap_penalty, int mismatch_penalty, lrsc_dp_result* results, char* cigar_arena,
                              uint64_t arena_cap, uint64_t* arena_used)
@@ -1337,113 +1525,6 @@ extern "C" int lrsc_dp_align(lrsc_ctx* ctx, const char* seq, uint64_t seq_len, c
     return LRSC_OK;
 }
 
-// The DP stage for a set of requests whose queries are already on the device: seeds -> (chunked by memory)
-// retrieve -> align -> MSA.  Results stay on the device (d_msa[i], consensus codes at d_cons + reqs[i].cons_off).
-struct DpStage {
-    DevBuf<DpRequest> d_reqs;
-    DevBuf<DpMsaOut> d_msa;
-    DevBuf<uint8_t> d_cons, d_strings, d_ops, d_trace;
-    DevBuf<DpJob> d_jobs;
-    DevBuf<DpAlignOut> d_align;
-    uint64_t cons_total = 0, n_strings = 0;
-
-    int run(lrsc_ctx* ctx, const uint8_t* d_query_codes, std::vector<DpRequest>& reqs)
-    {
-        const uint32_t n = (uint32_t)reqs.size();
-        n_strings = 0; cons_total = 0;
-        if(n == 0) return LRSC_OK;
-        for(DpRequest& r : reqs) {
-            if(r.k == 0 || r.lq < r.k) return fail(LRSC_ERR_ARG, "dp request: kmer_len must satisfy 1 <= kmer_len <= query length");
-            r.max_len = (uint32_t)(size_t)(r.lq * 1.1 + 20);                 // LongReadOverlap.cpp:618
-            r.str_cap = (std::max(r.max_len, r.k) + 3) & ~3u;
-            r.ops_cap = (r.lq + r.str_cap + 1 + 3) & ~3u;
-            r.cons_cap = dp_msa_columns(r.lq);
-            r.cons_off = cons_total;
-            cons_total += r.cons_cap;
-            if(((r.lq + 2 + 3) & ~3u) + r.str_cap + 8 > 64 * 1024) return fail(LRSC_ERR_UNSUPPORTED, "dp request: query longer than ~30 kb");
-            if(dp_msa_lds_bytes(r.lq, r.str_cap, r.ops_cap, r.coverage) > 160 * 1024)
-                return fail(LRSC_ERR_UNSUPPORTED, "dp request: query too long for the LDS-resident multiple alignment (~5 kb)");
-        }
-        HIP_TRY(d_reqs.reserve(n));
-        HIP_TRY(d_msa.reserve(n));
-        HIP_TRY(d_cons.reserve(cons_total));
-        HIP_TRY(hipMemcpyAsync(d_reqs.p, reqs.data(), (size_t)n * sizeof(DpRequest), hipMemcpyHostToDevice, ctx->stream));
-        DpPipeArgs a{};
-        a.codes = d_query_codes; a.reqs = d_reqs.p; a.n_reqs = n; a.ctr = ctx->d_ctr;
-        int st = timed_launch(ctx, LRSC_K_LF, [&]() { return launch_dp_seeds(ctx->fm, a, ctx->stream); });
-        if(st != LRSC_OK) return st;
-        HIP_TRY(hipMemcpy(reqs.data(), d_reqs.p, (size_t)n * sizeof(DpRequest), hipMemcpyDeviceToHost));
-
-        uint64_t budget = 16ull << 30;
-        if(const char* e = std::getenv("LRSC_DP_CHUNK_MB")) budget = std::max<uint64_t>(1, (uint64_t)std::atoll(e)) << 20;
-        const uint32_t n_waves = dp_wave_count(ctx);
-        uint32_t begin = 0;
-        while(begin < n) {
-            uint32_t end = begin, max1 = 1, max2 = 1, lds = 0;
-            uint64_t jobs = 0, sbytes = 0, obytes = 0;
-            while(end < n) {
-                DpRequest& r = reqs[end];
-                r.n_str = r.cnt[0] + r.cnt[1] + r.cnt[2] + r.cnt[3];
-                const uint64_t sb = (uint64_t)r.n_str * r.str_cap, ob = (uint64_t)r.n_str * r.ops_cap;
-                if(end > begin && sbytes + obytes + sb + ob + (jobs + r.n_str) * (sizeof(DpJob) + sizeof(DpAlignOut)) > budget) break;
-                r.job_first = jobs; r.str_off = sbytes; r.ops_off = obytes;
-                jobs += r.n_str; sbytes += sb; obytes += ob;
-                max1 = std::max(max1, r.lq); max2 = std::max(max2, r.str_cap);
-                lds = std::max(lds, dp_msa_lds_bytes(r.lq, r.str_cap, r.ops_cap, r.coverage));
-                ++end;
-            }
-            if(jobs >= (1ull << 32)) return fail(LRSC_ERR_UNSUPPORTED, "dp chunk: too many alignments");
-            const uint32_t nc = end - begin;
-            HIP_TRY(hipMemcpyAsync(d_reqs.p + begin, reqs.data() + begin, (size_t)nc * sizeof(DpRequest), hipMemcpyHostToDevice, ctx->stream));
-            HIP_TRY(d_strings.reserve(std::max<uint64_t>(sbytes, 64)));
-            HIP_TRY(d_ops.reserve(std::max<uint64_t>(obytes, 64)));
-            HIP_TRY(d_jobs.reserve(std::max<uint64_t>(jobs, 1)));
-            HIP_TRY(d_align.reserve(std::max<uint64_t>(jobs, 1)));
-            DpPipeArgs c = a;
-            c.reqs = d_reqs.p + begin; c.n_reqs = nc; c.n_jobs = jobs;
-            c.strings = d_strings.p; c.jobs = d_jobs.p; c.align = d_align.p; c.ops = d_ops.p;
-            c.cons = d_cons.p; c.msa = d_msa.p + begin; c.lds_bytes = lds;
-            st = timed_launch(ctx, LRSC_K_LF, [&]() { return launch_dp_retrieve(ctx->fm, c, ctx->stream); });
-            if(st != LRSC_OK) return st;
-            if(jobs) {
-                DpAlignArgs al{};
-                al.codes = d_query_codes; al.strings = d_strings.p; al.jobs = d_jobs.p; al.n_jobs = (uint32_t)jobs;
-                al.band_width = 200; al.match_score = 1; al.gap_penalty = -1; al.mismatch_penalty = -8;   // LongReadOverlap.cpp:635-643
-                al.ops = d_ops.p; al.out = d_align.p; al.max_s1 = max1; al.max_s2 = max2; al.reqs = c.reqs;
-                al.trace_stride = (uint64_t)(max1 + 17) * kDpTraceStride;
-                const uint32_t nw = (uint32_t)std::min<uint64_t>(n_waves, jobs);
-                HIP_TRY(d_trace.reserve(al.trace_stride * nw));
-                al.trace = d_trace.p;
-                st = timed_launch(ctx, LRSC_K_DP, [&]() { return launch_dp_align(al, nw, ctx->stream); });
-                if(st != LRSC_OK) return st;
-            }
-            if(std::getenv("LRSC_DP_DEBUG")) {
-                std::vector<DpAlignOut> ao(jobs);
-                std::vector<DpJob> jj(jobs);
-                (void)hipMemcpy(ao.data(), d_align.p, jobs * sizeof(DpAlignOut), hipMemcpyDeviceToHost);
-                (void)hipMemcpy(jj.data(), d_jobs.p, jobs * sizeof(DpJob), hipMemcpyDeviceToHost);
-                for(uint32_t i = begin; i < end && i < begin + 3; ++i) {
-                    const DpRequest& r = reqs[i];
-                    std::fprintf(stderr, "[dp] req %u lq %u k %u cov %u cnt %u %u %u %u rows %llu %llu %llu %llu n_str %u max_len %u\n", i, r.lq, r.k,
-                                 r.coverage, r.cnt[0], r.cnt[1], r.cnt[2], r.cnt[3], (unsigned long long)r.row_lo[0], (unsigned long long)r.row_lo[1],
-                                 (unsigned long long)r.row_lo[2], (unsigned long long)r.row_lo[3], r.n_str, r.max_len);
-                    for(uint32_t s = 0; s < r.n_str; ++s) {
-                        const DpAlignOut& o = ao[r.job_first + s];
-                        std::fprintf(stderr, "[dp]   str %u len %u mode %u skipped %u accept %u cols %d edit %d m0 %d-%d m1 %d-%d nops %u\n", s,
-                                     jj[r.job_first + s].s2_len, jj[r.job_first + s].mode, o.skipped, o.accept, o.total_columns, o.edit_distance,
-                                     o.m0s, o.m0e, o.m1s, o.m1e, o.n_ops);
-                    }
-                }
-            }
-            st = timed_launch(ctx, LRSC_K_MSA, [&]() { return launch_dp_msa(c, ctx->stream); });
-            if(st != LRSC_OK) return st;
-            n_strings += jobs;
-            begin = end;
-        }
-        return LRSC_OK;
-    }
-};
-
 extern "C" int lrsc_dp_consensus(lrsc_ctx* ctx, const char* seq, uint64_t seq_len, const lrsc_msa_query* queries, uint32_t n,
                                  lrsc_msa_result* results, char* arena, uint64_t arena_cap, uint64_t* arena_used)
 {
@@ -1475,7 +1556,7 @@ extern "C" int lrsc_dp_consensus(lrsc_ctx* ctx, const char* seq, uint64_t seq_le
     HIP_TRY(hipMemcpy(cons.data(), stage.d_cons.p, stage.cons_total, hipMemcpyDeviceToHost));
     uint64_t used = 0;
     for(uint32_t i = 0; i < n; ++i) {
-        if(mo[i].error) return fail(LRSC_ERR_CAPACITY, "msa: column capacity exceeded");
+        if(mo[i].error) return fail(LRSC_ERR_LIMIT, "msa: column capacity exceeded");
         results[i].n_rows = mo[i].n_rows; results[i].n_retrieved = reqs[i].n_str; results[i].cons_len = mo[i].cons_len; results[i].pad = 0;
         results[i].cons_off = used;
         if(arena && used + mo[i].cons_len <= arena_cap)

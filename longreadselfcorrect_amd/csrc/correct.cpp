@@ -83,12 +83,10 @@ extern "C" int lrsc_correct_reads(lrsc_ctx* ctx, const char* reads, const uint64
     const lrsc_params* params = &params_v;
     *n_pieces_out = 0; *out_used = 0;
     if(n_reads == 0) return LRSC_OK;
-    if(!params->no_dp) return LRSC_ERR_UNSUPPORTED;       // the DP/MSA fallback (correctByMSAlignment) is not in the product yet
-
     // Default: everything on the device (lrsc_batch_correct).  LRSC_CORRECT_MODE=rounds keeps the host-stitched
     // rounds below, which the tests run as an independent cross-check of the persistent kernel.
     const char* mode = std::getenv("LRSC_CORRECT_MODE");
-    if(!(mode && std::strcmp(mode, "rounds") == 0)) {
+    if(!(mode && std::strcmp(mode, "rounds") == 0) || !params->no_dp) {     // the rounds cross-check covers --nodp only
         lrsc_batch* db = nullptr;
         int dst = lrsc_batch_create(ctx, reads, read_off, n_reads, &db);
         if(dst != LRSC_OK) return dst;

@@ -3,11 +3,13 @@
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
 
+#include "dp_dev.h"
 #include "extend.h"
 
 namespace lrsc {
 
-enum { LRSC_WALK_ERR_GEOMETRY = -103, LRSC_WALK_ERR_OUTPUT = -104, LRSC_WALK_ERR_CODE = -105 };
+enum { LRSC_WALK_ERR_GEOMETRY = -103, LRSC_WALK_ERR_OUTPUT = -104, LRSC_WALK_ERR_CODE = -105, LRSC_WALK_ERR_DP = -106 };
+enum : uint32_t { kReadDone = 0, kReadParked = 1 };   // ReadOut::state: parked = waiting for the DP stage's answer
 
 constexpr uint32_t kMaxInitK = 59;       // initk + 2 = maxOverlap must stay below the 64-character suffix window
 
@@ -24,7 +26,7 @@ struct ReadWork {
     uint64_t piece_off;      // into piece_start
     uint32_t lq_max, pathw, out_cap, piece_cap;
     uint32_t o_item9f, o_item9r, o_next9f, o_next9r, o_head9, o_head5, o_next5, o_flags5, o_term, o_leaves, o_rings,
-        o_paths, o_results, o_query, o_best;
+        o_paths, o_results, o_query, o_best, o_dpq;
 };
 
 struct ReadOut {             // PacBioSelfCorrectionResult (PacBioSelfCorrectionProcess.h:58-94) without the strings
@@ -34,6 +36,11 @@ struct ReadOut {             // PacBioSelfCorrectionResult (PacBioSelfCorrection
     uint64_t cyc[4];         // s_memtime ticks in: query + prepare, trees + root, extension loop, stitching (LRSC_CORRECT_PROFILE)
     uint32_t n_pieces, out_len, merge;
     int32_t error;
+    // chain state of a parked read (pieceVec.back()'s SeedFeature fields + iterTarget) and its DP request
+    uint32_t state, it;
+    int32_t s_seed_len, s_end, s_end_best, s_max_fixed, s_is_repeat;
+    uint32_t dp_k, dp_lq;
+    int64_t dp_total_freq;       // source.maxFixedMerFreq + target.maxFixedMerFreq
 };
 
 struct CorrectArgs {
@@ -52,7 +59,13 @@ struct CorrectArgs {
     ReadPlan* plan;                  // plan kernel only
     // FMextendParameters / PacBioSelfCorrectionParameters
     uint32_t seed_size, min_overlap, max_leaves;
-    int32_t start_kmer_len, next_target, split;
+    int32_t start_kmer_len, next_target, split, no_dp;
+    // second and later launches: reads parked on a DP request pick up the answer
+    uint32_t resume;
+    const uint32_t* dp_index;        // read -> request
+    const DpRequest* dp_reqs;
+    const DpMsaOut* dp_msa;
+    const uint8_t* dp_cons;
     uint64_t pb_coverage;
     double pacbio_error_rate;
     const double* freqs_of_kmer_size;

@@ -36,13 +36,20 @@ __global__ __launch_bounds__(64, 2) void correct_reads_kernel(FmIndexDev fm, Cor
         uint8_t* out = a.out_codes + rw.out_off;
         uint32_t* piece_start = a.piece_start + rw.piece_off;
 
-        int64_t correctedLen = 0, totalWalkNum = 0, highErrorNum = 0, exceedDepthNum = 0, exceedLeaveNum = 0, FMNum = 0, seedDis = 0;
+        const bool resume = a.resume != 0;                                       // the read was parked waiting for its DP result
+        int64_t correctedLen = 0, totalWalkNum = 0, highErrorNum = 0, exceedDepthNum = 0, exceedLeaveNum = 0, FMNum = 0, DPNum = 0, seedDis = 0;
         uint32_t out_len = 0, n_pieces = 0;
         int error = 0;
+        uint32_t state = kReadDone;
         uint64_t cyc_prep = 0, cyc_stitch = 0;
-        R.cyc[1] = 0; R.cyc[2] = 0;
+        if(resume) {
+            correctedLen = R.c[1]; totalWalkNum = R.c[3]; highErrorNum = R.c[4]; exceedDepthNum = R.c[5]; exceedLeaveNum = R.c[6];
+            FMNum = R.c[7]; DPNum = R.c[8]; seedDis = R.c[9];
+            out_len = R.out_len; n_pieces = R.n_pieces;
+            cyc_prep = R.cyc[0];
+        } else { R.cyc[0] = 0; R.cyc[1] = 0; R.cyc[2] = 0; R.cyc[3] = 0; R.steps = 0; }
 
-        if(n_seeds >= 2) {
+        if(n_seeds >= 2 && !(resume && R.state != kReadParked)) {
             uint8_t* ws = a.workspace + rw.ws_off;
             Walk<WIDE> W;
             W.sF = strand_consts<P>(fm.strand[LRSC_RBWT]);
@@ -74,15 +81,63 @@ __global__ __launch_bounds__(64, 2) void correct_reads_kernel(FmIndexDev fm, Cor
             uint8_t* q = ws + rw.o_query;
             uint32_t* best = reinterpret_cast<uint32_t*>(ws + rw.o_best);
             W.q = q;
-            W.n_rank = 0; W.n_blk = 0; W.steps = 0; W.error = 0; W.cyc_setup = 0; W.cyc_loop = 0;
+            W.n_rank = 0; W.n_blk = 0; W.steps = R.steps; W.error = 0; W.cyc_setup = R.cyc[1]; W.cyc_loop = R.cyc[2];
+            uint8_t* dpq = ws + rw.o_dpq;                                          // the parked DP query lives here between launches
 
-            // pieceVec.push_back(seedVec[0])
-            piece_start[n_pieces++] = 0;
-            for(int t = 0; t < seeds[1]; ++t) out[out_len++] = read[seeds[0] + t];
             // source = pieceVec.back(): the SeedFeature fields the loop reads (SeedFeature.h:22-45)
-            int S_seedLen = seeds[1], S_end = seeds[0] + seeds[1] - 1, S_endBest = seeds[5];
-            bool S_isRepeat = (seeds[3] & 1) != 0;
-            uint32_t it = 1;
+            int S_seedLen, S_end, S_endBest, S_maxFixed;
+            bool S_isRepeat;
+            uint32_t it;
+            if(!resume) {
+                // pieceVec.push_back(seedVec[0])
+                piece_start[n_pieces++] = 0;
+                for(int t = 0; t < seeds[1]; ++t) out[out_len++] = read[seeds[0] + t];
+                S_seedLen = seeds[1]; S_end = seeds[0] + seeds[1] - 1; S_endBest = seeds[5]; S_maxFixed = seeds[2];
+                S_isRepeat = (seeds[3] & 1) != 0;
+                it = 1;
+            } else {
+                S_seedLen = R.s_seed_len; S_end = R.s_end; S_endBest = R.s_end_best; S_maxFixed = R.s_max_fixed; S_isRepeat = R.s_is_repeat != 0;
+                it = R.it;
+                // correctByMSAlignment's tail (:237-244) with the DP stage's answer for target = *iterTarget
+                const uint32_t di = a.dp_index[r];
+                const DpMsaOut m = a.dp_msa[di];
+                const int32_t* T0 = seeds + (uint64_t)it * kSeedInts;
+                if(m.error) error = LRSC_WALK_ERR_DP;
+                else if(m.n_rows > 3) {
+                    const uint8_t* cons = a.dp_cons + a.dp_reqs[di].cons_off;
+                    if(m.cons_len < R.dp_k) error = LRSC_WALK_ERR_DP;                // out.erase(0, k) would throw in the reference
+                    else {
+                        const uint32_t appended = m.cons_len - R.dp_k;
+                        if(out_len + appended > rw.out_cap) error = LRSC_WALK_ERR_OUTPUT;
+                        else {
+                            for(uint32_t j = 0; j < appended; ++j) out[out_len + j] = cons[R.dp_k + j];
+                            out_len += appended;
+                            correctedLen += appended;
+                            seedDis += T0[0] - S_end - 1;
+                            DPNum++;
+                            S_seedLen += (int)appended;
+                        }
+                    }
+                } else if(a.split) {
+                    if(out_len + (uint32_t)T0[1] > rw.out_cap) error = LRSC_WALK_ERR_OUTPUT;
+                    else {
+                        piece_start[n_pieces++] = out_len;
+                        for(int t = 0; t < T0[1]; ++t) out[out_len++] = read[T0[0] + t];
+                        S_seedLen = T0[1];
+                        correctedLen += T0[1];
+                    }
+                } else {
+                    const int raw = (T0[0] + T0[1] - 1) - S_end;
+                    if(out_len + (uint32_t)raw > rw.out_cap) error = LRSC_WALK_ERR_OUTPUT;
+                    else {
+                        for(int t = 0; t < raw; ++t) out[out_len++] = read[S_end + 1 + t];
+                        S_seedLen += raw;
+                        correctedLen += T0[1];
+                    }
+                }
+                S_end = T0[0] + T0[1] - 1; S_endBest = T0[5]; S_isRepeat = (T0[3] & 1) != 0; S_maxFixed = T0[2];
+                it += 1;
+            }
             int next = 0, firstType = 0;
             const int min_SA = a.pb_coverage > 60 ? (int)((a.pb_coverage / 60) * 3) : 3;
 
@@ -165,7 +220,7 @@ __global__ __launch_bounds__(64, 2) void correct_reads_kernel(FmIndexDev fm, Cor
                     FMNum++;
                     totalWalkNum++;
                     S_seedLen += (int)appended;                                      // SeedFeature::append
-                    S_end = T_start + T_len - 1; S_endBest = T[5]; S_isRepeat = T_isRepeat;
+                    S_end = T_start + T_len - 1; S_endBest = T[5]; S_isRepeat = T_isRepeat; S_maxFixed = T[2];
                     it += (uint32_t)next + 1;
                     next = 0;
                     continue;
@@ -180,6 +235,24 @@ __global__ __launch_bounds__(64, 2) void correct_reads_kernel(FmIndexDev fm, Cor
                 if(error) break;
                 totalWalkNum++;
                 const int32_t* T0 = seeds + (uint64_t)it * kSeedInts;               // target = *iterTarget
+                if(!a.no_dp) {
+                    // correctByMSAlignment (:208-236): park the read with its query = src k-mer + raw segment + target seed
+                    const int iv0 = T0[0] - S_end - 1;
+                    int k0 = (S_endBest < T0[4] ? S_endBest : T0[4]) - 2;
+                    if(S_isRepeat || (T0[3] & 1)) {
+                        k0 = S_seedLen < T0[1] ? S_seedLen : T0[1];
+                        k0 = k0 < a.start_kmer_len + 2 ? k0 : a.start_kmer_len + 2;
+                    }
+                    if(k0 < 1 || k0 > S_seedLen || k0 > T0[1] || iv0 < 0 || (uint32_t)(k0 + iv0 + T0[1]) > rw.lq_max) { error = LRSC_WALK_ERR_GEOMETRY; break; }
+                    const uint8_t* tl = out + out_len - k0;
+                    for(int t = 0; t < k0; ++t) dpq[t] = tl[t];
+                    for(int t = 0; t < iv0; ++t) dpq[k0 + t] = read[S_end + 1 + t];
+                    for(int t = 0; t < T0[1]; ++t) dpq[k0 + iv0 + t] = read[T0[0] + t];
+                    R.dp_k = (uint32_t)k0; R.dp_lq = (uint32_t)(k0 + iv0 + T0[1]);
+                    R.dp_total_freq = (int64_t)S_maxFixed + (int64_t)T0[2];
+                    state = kReadParked;
+                    break;
+                }
                 if(a.split) {
                     if(out_len + (uint32_t)T0[1] > rw.out_cap) { error = LRSC_WALK_ERR_OUTPUT; break; }
                     piece_start[n_pieces++] = out_len;                               // pieceVec.push_back(target)
@@ -192,20 +265,22 @@ __global__ __launch_bounds__(64, 2) void correct_reads_kernel(FmIndexDev fm, Cor
                     S_seedLen += raw;
                 }
                 correctedLen += T0[1];
-                S_end = T0[0] + T0[1] - 1; S_endBest = T0[5]; S_isRepeat = (T0[3] & 1) != 0;
+                S_end = T0[0] + T0[1] - 1; S_endBest = T0[5]; S_isRepeat = (T0[3] & 1) != 0; S_maxFixed = T0[2];
                 it += 1;
                 next = 0;
             }
             n_rank = W.n_rank; n_blk = W.n_blk;
             R.steps = W.steps;
+            cyc_stitch = __builtin_readcyclecounter() - t_all0 - (cyc_prep - R.cyc[0]) - (W.cyc_setup - R.cyc[1]) - (W.cyc_loop - R.cyc[2]);
             R.cyc[1] = W.cyc_setup; R.cyc[2] = W.cyc_loop;
-            cyc_stitch = __builtin_readcyclecounter() - t_all0 - cyc_prep - W.cyc_setup - W.cyc_loop;
-        } else
-            R.steps = 0;
+            R.it = it; R.s_seed_len = S_seedLen; R.s_end = S_end; R.s_end_best = S_endBest; R.s_max_fixed = S_maxFixed;
+            R.s_is_repeat = S_isRepeat ? 1 : 0;
+        }
         R.c[0] = rlen; R.c[1] = correctedLen; R.c[2] = n_seeds; R.c[3] = totalWalkNum; R.c[4] = highErrorNum;
-        R.c[5] = exceedDepthNum; R.c[6] = exceedLeaveNum; R.c[7] = FMNum; R.c[8] = 0; R.c[9] = seedDis;
-        R.cyc[0] = cyc_prep; R.cyc[3] = cyc_stitch;
+        R.c[5] = exceedDepthNum; R.c[6] = exceedLeaveNum; R.c[7] = FMNum; R.c[8] = DPNum; R.c[9] = seedDis;
+        R.cyc[0] = cyc_prep; R.cyc[3] += cyc_stitch;
         R.n_pieces = n_pieces; R.out_len = out_len; R.merge = n_pieces != 0; R.error = error;
+        R.state = error ? kReadDone : state;
     }
     flush_counters(a.ctr, n_rank, n_blk);
 }

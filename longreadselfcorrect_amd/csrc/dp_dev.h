@@ -41,6 +41,7 @@ struct DpRequest {
     uint64_t row_lo[4];           // retrieveStr start rows: 0 = fwd interval of the source k-mer (rbwt), 1 = its rvc interval (bwt),
     uint32_t cnt[4];              //                         2 / 3 = the same for the reverse-complemented target k-mer
     uint32_t lq, k, max_len, str_cap, ops_cap, cons_cap, n_str;
+    uint32_t w_cols;              // column capacity of the multiple alignment (query + gap columns), grown on overflow
     uint32_t min_overlap, coverage;
     int32_t min_call_coverage;
     double min_identity;
@@ -65,6 +66,8 @@ struct DpPipeArgs {
     uint8_t* cons;
     DpMsaOut* msa;
     uint32_t lds_bytes;           // dynamic LDS of the MSA kernel (sized for the largest request)
+    const uint32_t* req_list;     // optional: run the MSA kernel for these n_list requests only (overflow retries)
+    uint32_t n_list;
     DevCounters* ctr;
 };
 
@@ -91,8 +94,8 @@ hipError_t launch_dp_seeds(const FmIndexDev& fm, const DpPipeArgs& a, hipStream_
 hipError_t launch_dp_retrieve(const FmIndexDev& fm, const DpPipeArgs& a, hipStream_t stream);
 // wavefront per request: MultipleAlignment::addOverlap for every accepted overlap + calculateBaseConsensus
 hipError_t launch_dp_msa(const DpPipeArgs& a, hipStream_t stream);
-uint32_t dp_msa_lds_bytes(uint32_t lq, uint32_t str_cap, uint32_t ops_cap, uint32_t coverage);
-// column capacity of one multiple alignment: the query plus the gap columns insertions may open
+uint32_t dp_msa_lds_bytes(uint32_t w_cols, uint32_t str_cap, uint32_t ops_cap, uint32_t coverage);
+// initial column capacity of one multiple alignment: the query plus the gap columns insertions may open
 constexpr uint32_t dp_msa_columns(uint32_t lq) { return 2 * lq + 128; }
 
 } // namespace lrsc

@@ -29,9 +29,9 @@ __device__ __forceinline__ uint32_t mbcnt(uint64_t mask)
 }
 } // namespace
 
-uint32_t dp_msa_lds_bytes(uint32_t lq, uint32_t str_cap, uint32_t ops_cap, uint32_t coverage)
+uint32_t dp_msa_lds_bytes(uint32_t w_cols, uint32_t str_cap, uint32_t ops_cap, uint32_t coverage)
 {
-    const uint32_t W = dp_msa_columns(lq), E = 4 * coverage + 4;
+    const uint32_t W = w_cols, E = 4 * coverage + 4;
     uint32_t o = 0;
     o += W * (uint32_t)sizeof(Cnt);        // cnt
     o += E * 8;                            // lead, size
@@ -46,9 +46,11 @@ __global__ __launch_bounds__(64) void dp_msa_kernel(DpPipeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t lane = lane_id();
-    for(uint32_t rq = blockIdx.x; rq < a.n_reqs; rq += gridDim.x) {
+    const uint32_t n_work = a.req_list ? a.n_list : a.n_reqs;
+    for(uint32_t wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+        const uint32_t rq = a.req_list ? a.req_list[wi] : wi;
         const DpRequest R = a.reqs[rq];
-        const uint32_t W = dp_msa_columns(R.lq), E = 4 * R.coverage + 4;
+        const uint32_t W = R.w_cols, E = 4 * R.coverage + 4;
         Cnt* cnt = reinterpret_cast<Cnt*>(smem);
         uint32_t* lead = reinterpret_cast<uint32_t*>(smem + W * sizeof(Cnt));
         uint32_t* size = lead + E;
@@ -204,11 +206,11 @@ __global__ __launch_bounds__(64) void dp_msa_kernel(DpPipeArgs a)
                 }
                 cons_len += (uint32_t)__builtin_popcountll(m);
             }
-            if(cons_len > R.cons_cap) overflow = true;
+            if(cons_len > R.cons_cap) { overflow = true; cons_len = 0xFFFFFFFFu; }
         }
         if(lane == 0) {
             DpMsaOut o;
-            o.n_rows = n_rows; o.cons_len = overflow ? 0 : cons_len; o.error = overflow ? 1u : 0u; o.pad = 0;
+            o.n_rows = n_rows; o.cons_len = overflow ? 0 : cons_len; o.error = !overflow ? 0u : cons_len == 0xFFFFFFFFu ? 2u : 1u; o.pad = 0;
             a.msa[rq] = o;
         }
     }
@@ -229,7 +231,9 @@ hipError_t launch_dp_msa(const DpPipeArgs& a, hipStream_t stream)
     uint32_t per_cu = a.lds_bytes ? (160u * 1024u) / a.lds_bytes : 16u;
     per_cu = per_cu < 1 ? 1 : per_cu > 16 ? 16 : per_cu;
     uint32_t n_waves = (uint32_t)cus * per_cu;
-    if(n_waves > a.n_reqs) n_waves = a.n_reqs;
+    const uint32_t n_work = a.req_list ? a.n_list : a.n_reqs;
+    if(n_work == 0) return hipSuccess;
+    if(n_waves > n_work) n_waves = n_work;
     hipLaunchKernelGGL(dp_msa_kernel, dim3(n_waves), dim3(64), a.lds_bytes, stream, a);
     return hipGetLastError();
 }

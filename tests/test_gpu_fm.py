@@ -302,6 +302,38 @@ def correct_mode(request, monkeypatch):
     return request.param
 
 
+def _check_whole_path(api, index, oracle, ds, p, n_reads=None, min_fm=500, min_dp=0):
+    off = ds.off if n_reads is None else ds.off[: n_reads + 1].copy()
+    bases = ds.bases[: int(off[-1])]
+    reads = ds.reads[: len(off) - 1]
+    ob, orb = oracle.bwt_load(ds.prefix + ".bwt"), oracle.bwt_load(ds.prefix + ".rbwt")
+    want = oracle.correct_reads(ob, orb, p, bases, off)
+    ctx = index.ctx(p, 0)
+    results, pieces = ctx.correct_reads(bases, off)
+    ctx.close()
+    cfa, dfa = _fasta(results, pieces, reads, p.split)
+    assert cfa == want.correct_fa
+    assert dfa == want.discard_fa
+    names = ("total_reads_len", "corrected_len", "total_seed_num", "total_walk_num", "high_error_num", "exceed_depth_num",
+             "exceed_leave_num", "fm_num", "dp_num", "seed_dis", "merge")
+    got = np.array([[getattr(r, n) for n in names] for r in results], dtype=np.int64)
+    np.testing.assert_array_equal(got, want.counters)
+    assert got[:, 7].sum() > min_fm and (got[:, 4].sum() + got[:, 5].sum()) > 0      # many FM walks, some failures
+    assert got[:, 8].sum() >= min_dp
+    want.close(); ob.close(); orb.close()
+    return got
+
+
+@pytest.mark.parametrize("genome,cov,split,next_target", [(5, 90, 0, 1), (5, 90, 1, 1), (10, 90, 0, 1), (5, 90, 0, 2)])
+def test_whole_path_with_dp_fallback_matches_oracle_fasta(api, gpu_index, oracle, small_ds, genome, cov, split, next_target):
+    """The DEFAULT pbcorrect flow (no --nodp): walks the FM-extension gives up on go through correctByMSAlignment
+    (LF-walk retrieval, banded DP, multiple alignment, consensus -- all on the device); correct.fa / discard.fa and all
+    counters incl. DPNum bit-identical to the oracle."""
+    p = api.params_default(genome, cov)
+    p.no_dp, p.split, p.next_target = 0, split, next_target
+    _check_whole_path(api, gpu_index, oracle, small_ds, p, min_fm=300, min_dp=20)
+
+
 @pytest.mark.parametrize("genome,cov,split,next_target", [(5, 90, 0, 1), (5, 90, 1, 1), (10, 90, 0, 1), (5, 90, 0, 3), (5, 90, 1, 2)])
 def test_whole_path_nodp_matches_oracle_fasta(api, gpu_index, oracle, small_ds, genome, cov, split, next_target, correct_mode):
     """correct.fa / discard.fa and every integer counter of PacBioSelfCorrectionResult, bit-identical to the
@@ -322,17 +354,6 @@ def test_whole_path_nodp_matches_oracle_fasta(api, gpu_index, oracle, small_ds, 
     np.testing.assert_array_equal(got, want.counters)
     assert got[:, 7].sum() > 500 and (got[:, 4].sum() + got[:, 5].sum()) > 0      # many FM walks, some failures
     want.close(); ob.close(); orb.close()
-
-
-def test_dp_mode_is_refused_not_faked(api, gpu_index, small_ds):
-    from longreadselfcorrect_amd import LrscError
-
-    p = api.params_default(5, 90)            # no_dp = 0: needs the DP/MSA fallback
-    ctx = gpu_index.ctx(p, 0)
-    with pytest.raises(LrscError) as ei:
-        ctx.correct_reads(small_ds.bases[: int(small_ds.off[2])], small_ds.off[:3].copy())
-    assert ei.value.status == -7
-    ctx.close()
 
 
 # ---- repeat-rich data: mode-2 attributes, isRepeat seeds, repeat-to-unique (reverse-strand) walks ---------------
@@ -511,3 +532,9 @@ def test_dp_consensus_matches_oracle(api, gpu_index, oracle, small_ds, cov):
         n_multi += want[0] > 3
     assert n_multi >= 10                                   # real pile-ups, not only "too few rows"
     ob.close(); orb.close()
+
+
+def test_repeat_dataset_with_dp_fallback(api, rep_index, oracle, repeat_ds):
+    p = api.params_default(5, 90)
+    p.no_dp = 0
+    _check_whole_path(api, rep_index, oracle, repeat_ds, p, n_reads=120, min_fm=100, min_dp=5)
