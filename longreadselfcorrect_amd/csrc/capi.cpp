@@ -121,6 +121,7 @@ struct lrsc_batch {
     unsigned long long* d_flags = nullptr;
     uint32_t* d_zeros = nullptr;
     uint8_t* d_attr = nullptr;
+    unsigned long long* d_start_bits = nullptr;
     int32_t* d_seeds = nullptr;
     uint32_t* d_seed_count = nullptr;
     float* d_thr = nullptr;
@@ -666,7 +667,7 @@ extern "C" void lrsc_batch_destroy(lrsc_batch* b)
     if(b->d_codes) (void)hipFree(b->d_codes);
     if(b->d_off) (void)hipFree(b->d_off);
     if(b->d_chunk) (void)hipFree(b->d_chunk);
-    void* ptrs[] = {b->d_freq, b->d_base_counted, b->d_valid, b->d_flags, b->d_zeros, b->d_attr, b->d_seeds,
+    void* ptrs[] = {b->d_freq, b->d_base_counted, b->d_valid, b->d_flags, b->d_zeros, b->d_attr, b->d_start_bits, b->d_seeds,
                     b->d_seed_count, b->d_thr, b->d_scan_tmp};
     for(void* q : ptrs) if(q) (void)hipFree(q);
     delete b;
@@ -815,6 +816,7 @@ static int batch_setup_seeds(lrsc_ctx* ctx, lrsc_batch* b)
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_flags), b->total_bases * sizeof(unsigned long long)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_zeros), b->total_bases * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_attr), b->total_bases));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_start_bits), ((b->total_bases + 255) / 256) * 4 * sizeof(unsigned long long)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_seeds), b->seed_cap * kSeedInts * sizeof(int32_t)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_seed_count), (size_t)b->n_reads * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_thr), 3 * 52 * sizeof(float)));
@@ -838,7 +840,7 @@ static SeedArgs batch_seed_args(const lrsc_ctx* ctx, const lrsc_batch* b)
     for(int i = 0; i < 3; ++i) a.offset[i] = p.offset[i];
     a.hh_ratio = p.hh_ratio;
     a.thresholds = b->d_thr;
-    a.flags = b->d_flags; a.zeros = b->d_zeros; a.attribute = b->d_attr; a.seeds = b->d_seeds; a.seed_count = b->d_seed_count;
+    a.flags = b->d_flags; a.zeros = b->d_zeros; a.attribute = b->d_attr; a.start_bits = b->d_start_bits; a.seeds = b->d_seeds; a.seed_count = b->d_seed_count;
     return a;
 }
 

@@ -65,6 +65,7 @@ struct SeedArgs {
     unsigned long long* flags;    // [pos] (repeat) | (garbage << 32), later its inclusive scan
     uint32_t* zeros;              // [pos] zero-frequency non-low-complexity scan k-mers, later its inclusive scan
     uint8_t* attribute;           // [pos] 1 unique / 2 repeat (LongReadProbe::getSeqAttribute)
+    unsigned long long* start_bits;   // bit pos: the static k-mer at pos passes the scan's first-iteration tests (a seed can start here)
     int32_t* seeds;               // kSeedInts per seed, read r's slab starts at seed_slab(r)
     uint32_t* seed_count;         // [read]
 };

@@ -14,6 +14,7 @@
 // the file is compiled with -ffp-contract=off.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
+#include <stdlib.h>
 
 #include "kernels.h"
 #include "rank_device.h"
@@ -72,31 +73,56 @@ __global__ __launch_bounds__(256) void seed_modes_kernel(SeedArgs a)
 __global__ __launch_bounds__(256) void seed_attribute_kernel(SeedArgs a)
 {
     const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if(gid >= a.total_bases) return;
-    uint32_t r = a.chunk_read[gid >> kChunkShift];
-    while(a.read_off[r + 1] <= gid) ++r;
-    const int64_t s = (int64_t)a.read_off[r], e = (int64_t)a.read_off[r + 1];
-    uint8_t attr = 1;
-    if(a.manual) {
-        attr = (uint8_t)a.mode;
-    } else if(e - s >= a.start_kmer_len) {
-        const int range = 300;
-        int64_t left = (int64_t)gid - (range >> 1), right = (int64_t)gid + (range >> 1);
-        left = left > s ? left : s;
-        right = right < e - 1 ? right : e - 1;
-        const unsigned long long wr = a.flags[right];
-        const unsigned long long wl = left > 0 ? a.flags[left - 1] : 0ull;
-        const unsigned long long d = wr - wl;                      // both halves are monotone: no borrow across bit 32
-        const int box2 = (int)(uint32_t)(d & 0xFFFFFFFFull);
-        int boxneg = (int)(uint32_t)(d >> 32);
-        const uint32_t zl = left > 0 ? a.zeros[left - 1] : 0u;
-        const uint32_t zs = s > 0 ? a.zeros[s - 1] : 0u;
-        boxneg -= (int)(zl - zs);                                   // zero-frequency k-mers that already left
-        const int size = (int)(right - left + 1) - boxneg;
-        const float ratio = (float)((double)((float)box2 / (float)size) + 0.0005);
-        if((double)ratio >= 0.02) attr = 2;
+    bool start_ok = false;
+    if(gid < a.total_bases) {
+        uint32_t r = a.chunk_read[gid >> kChunkShift];
+        while(a.read_off[r + 1] <= gid) ++r;
+        const int64_t s = (int64_t)a.read_off[r], e = (int64_t)a.read_off[r + 1];
+        uint8_t attr = 1;
+        if(a.manual) {
+            attr = (uint8_t)a.mode;
+        } else if(e - s >= a.start_kmer_len) {
+            const int range = 300;
+            int64_t left = (int64_t)gid - (range >> 1), right = (int64_t)gid + (range >> 1);
+            left = left > s ? left : s;
+            right = right < e - 1 ? right : e - 1;
+            const unsigned long long wr = a.flags[right];
+            const unsigned long long wl = left > 0 ? a.flags[left - 1] : 0ull;
+            const unsigned long long d = wr - wl;                      // both halves are monotone: no borrow across bit 32
+            const int box2 = (int)(uint32_t)(d & 0xFFFFFFFFull);
+            int boxneg = (int)(uint32_t)(d >> 32);
+            const uint32_t zl = left > 0 ? a.zeros[left - 1] : 0u;
+            const uint32_t zs = s > 0 ? a.zeros[s - 1] : 0u;
+            boxneg -= (int)(zl - zs);                                   // zero-frequency k-mers that already left
+            const int size = (int)(right - left + 1) - boxneg;
+            const float ratio = (float)((double)((float)box2 / (float)size) + 0.0005);
+            if((double)ratio >= 0.02) attr = 2;
+        }
+        a.attribute[gid] = attr;
+        // Can the greedy scan start a seed here?  Its first inner iteration (currPos == initPos, dynamicKmer == staticKmer,
+        // LongReadProbe.cpp:61-80) only looks at this position: not fake, frequency >= the mode's threshold, both strands
+        // valid, size within the bound (freqDiff is 1 there).  Everywhere else the scan just moves on, so it can jump.
+        if(e - s >= a.start_kmer_len) {
+            const int staticSize = a.start_kmer_len + a.offset[attr];
+            const int row = a.row_of_k[staticSize & 63];
+            const int sf = a.freq[(uint64_t)row * a.total_bases + gid];
+            start_ok = sf >= 0 && !((float)sf < a.thresholds[attr * 52 + staticSize]) && ((a.valid_mask[gid] >> row) & 1u) &&
+                       !(staticSize > a.kmer_len_up_bound);
+        }
     }
-    a.attribute[gid] = attr;
+    const unsigned long long m = __ballot(start_ok);
+    if((threadIdx.x & 63) == 0) a.start_bits[gid >> 6] = m;
+}
+
+// first position >= g (global) whose start bit is set, or gend
+__device__ __forceinline__ uint64_t next_start(const unsigned long long* __restrict__ bits, uint64_t g, uint64_t gend)
+{
+    while(g < gend) {
+        const unsigned long long w = bits[g >> 6] >> (g & 63);
+        if(w) { g += (uint64_t)__builtin_ctzll(w); return g < gend ? g : gend; }
+        g = (g | 63) + 1;
+    }
+    return gend;
 }
 
 // ---- 4. the greedy scan ---------------------------------------------------------------------------------
@@ -122,7 +148,7 @@ __device__ __forceinline__ int64_t find_run(const StrandC<typename Lay<WIDE>::po
     return iv_freq(iv);
 }
 
-constexpr uint32_t kReadsPerWave = 16;
+constexpr uint32_t kReadsPerWaveDefault = 32;       // LRSC_SEED_RPW overrides (power of two <= 64)
 
 struct DynKmer {          // the part of KmerFeature the scan needs
     int size;
@@ -131,7 +157,7 @@ struct DynKmer {          // the part of KmerFeature the scan needs
 };
 
 template <bool WIDE>
-__global__ __launch_bounds__(64) void seed_scan_kernel(FmIndexDev fm, SeedArgs a, uint32_t min_k, DevCounters* ctr)
+__global__ __launch_bounds__(64) void seed_scan_kernel(FmIndexDev fm, SeedArgs a, uint32_t min_k, uint32_t kReadsPerWave, DevCounters* ctr)
 {
     using P = typename Lay<WIDE>::pos_t;
     __shared__ __attribute__((aligned(16))) uint32_t mtab[MaskTabSize<WIDE>::value];
@@ -156,6 +182,8 @@ __global__ __launch_bounds__(64) void seed_scan_kernel(FmIndexDev fm, SeedArgs a
 
         if(len >= staticSize) {
             for(int64_t initPos = 0; initPos < len; initPos++) {
+                initPos = (int64_t)(next_start(a.start_bits, s + (uint64_t)initPos, e) - s);     // positions in between only do initPos++
+                if(initPos >= len) break;
                 const int dynamicMode = attr[initPos];
                 staticSize += a.offset[dynamicMode];
                 const int row = a.row_of_k[staticSize & 63];
@@ -319,9 +347,14 @@ hipError_t launch_seed_attribute(const SeedArgs& a, hipStream_t stream)
 hipError_t launch_seed_scan(const FmIndexDev& fm, const SeedArgs& a, uint32_t min_k, DevCounters* ctr, hipStream_t stream)
 {
     if(a.n_reads == 0) return hipSuccess;
-    const unsigned nb = (a.n_reads + kReadsPerWave - 1) / kReadsPerWave;
-    if(fm.wide) hipLaunchKernelGGL(seed_scan_kernel<true>, dim3(nb), dim3(64), 0, stream, fm, a, min_k, ctr);
-    else        hipLaunchKernelGGL(seed_scan_kernel<false>, dim3(nb), dim3(64), 0, stream, fm, a, min_k, ctr);
+    uint32_t rpw = kReadsPerWaveDefault;
+    if(const char* e = getenv("LRSC_SEED_RPW")) {
+        const int v = atoi(e);
+        if(v >= 1 && v <= 64 && (v & (v - 1)) == 0) rpw = (uint32_t)v;
+    }
+    const unsigned nb = (a.n_reads + rpw - 1) / rpw;
+    if(fm.wide) hipLaunchKernelGGL(seed_scan_kernel<true>, dim3(nb), dim3(64), 0, stream, fm, a, min_k, rpw, ctr);
+    else        hipLaunchKernelGGL(seed_scan_kernel<false>, dim3(nb), dim3(64), 0, stream, fm, a, min_k, rpw, ctr);
     return hipGetLastError();
 }
 hipError_t scan_seed_flags(unsigned long long* flags, uint32_t* zeros, uint64_t n, void** tmp, size_t* tmp_cap, hipStream_t stream)

@@ -99,10 +99,11 @@ def test_non_acgt_read_is_fatal_like_the_reference(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("split", [False, True])
-def test_stride_index_and_pbcorrect_end_to_end(stride, api, oracle, small_ds, tmp_path, split):
-    """`stride index` + `stride pbcorrect --nodp -c 90 -g 5`: index files byte-equal to ropebwt2's,
-    correct.fa / discard.fa and the integer lines of the stdout statistics equal to the oracle's."""
+@pytest.mark.parametrize("split,nodp", [(False, True), (True, True), (False, False)])
+def test_stride_index_and_pbcorrect_end_to_end(stride, api, oracle, small_ds, tmp_path, split, nodp):
+    """`stride index` + `stride pbcorrect -c 90 -g 5 [--nodp] [--split]`: index files byte-equal to ropebwt2's,
+    correct.fa / discard.fa and the integer lines of the stdout statistics equal to the oracle's -- with the
+    reference's default DP/MSA fallback too."""
     fa = tmp_path / "reads.fa"
     write_fasta(fa, small_ds.reads)
     prefix = tmp_path / "idx"
@@ -110,13 +111,15 @@ def test_stride_index_and_pbcorrect_end_to_end(stride, api, oracle, small_ds, tm
     for ext in ("bwt", "rbwt"):
         assert open(f"{prefix}.{ext}", "rb").read() == open(f"{small_ds.prefix}.{ext}", "rb").read()
     out = tmp_path / "out"
-    cmd = [stride, "pbcorrect", "-p", str(prefix), "-o", str(out), "-c", "90", "-g", "5", "--nodp", "--batch", "70"]
+    cmd = [stride, "pbcorrect", "-p", str(prefix), "-o", str(out), "-c", "90", "-g", "5", "--batch", "70"]
+    if nodp:
+        cmd.append("--nodp")
     if split:
         cmd.append("--split")
     r = subprocess.run(cmd + [str(fa)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     p = api.params_default(5, 90)
-    p.no_dp, p.split = 1, int(split)
+    p.no_dp, p.split = int(nodp), int(split)
     ob, orb = oracle.bwt_load(small_ds.prefix + ".bwt"), oracle.bwt_load(small_ds.prefix + ".rbwt")
     want = oracle.correct_reads(ob, orb, p, small_ds.bases, small_ds.off)
     assert (out / "correct.fa").read_text() == want.correct_fa
