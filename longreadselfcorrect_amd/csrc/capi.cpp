@@ -1114,13 +1114,11 @@ struct DpStage {
             r.max_len = (uint32_t)(size_t)(r.lq * 1.1 + 20);                 // LongReadOverlap.cpp:618
             r.str_cap = (std::max(r.max_len, r.k) + 3) & ~3u;
             r.ops_cap = (r.lq + r.str_cap + 1 + 3) & ~3u;
-            r.cons_cap = dp_msa_columns(r.lq);
+            r.cons_cap = dp_cons_capacity(r.lq);
             r.w_cols = dp_msa_columns(r.lq);
             r.cons_off = cons_total;
             cons_total += r.cons_cap;
             if(((r.lq + 2 + 3) & ~3u) + r.str_cap + 8 > 64 * 1024) return fail(LRSC_ERR_UNSUPPORTED, "dp request: query longer than ~30 kb");
-            if(dp_msa_lds_bytes(r.w_cols, r.str_cap, r.ops_cap, r.coverage) > 160 * 1024)
-                return fail(LRSC_ERR_UNSUPPORTED, "dp request: query too long for the LDS-resident multiple alignment (~5 kb)");
         }
         HIP_TRY(d_reqs.reserve(n));
         HIP_TRY(d_msa.reserve(n));
@@ -1193,34 +1191,53 @@ struct DpStage {
                     }
                 }
             }
-            st = timed_launch(ctx, LRSC_K_MSA, [&]() { return launch_dp_msa(c, ctx->stream); });
-            if(st != LRSC_OK) return st;
-            // a pile-up that opened more gap columns than its capacity is redone with twice the columns
+            // multiple alignments: one launch per LDS-size bucket (a wide pile-up must not cut everyone's occupancy), a
+            // global-memory variant for the few that exceed 160 KB; a pile-up that opened more gap columns than its
+            // capacity is redone with twice the columns.
             std::vector<DpMsaOut> mo(nc);
-            std::vector<uint32_t> redo;
-            DevBuf<uint32_t> d_redo;
-            for(;;) {
+            std::vector<uint32_t> todo(nc), list;
+            for(uint32_t i = 0; i < nc; ++i) todo[i] = i;
+            DevBuf<uint32_t> d_list;
+            DevBuf<uint8_t> d_msa_ws;
+            HIP_TRY(d_list.reserve(nc));
+            while(!todo.empty()) {
+                static const uint32_t kBuckets[] = {16u << 10, 24u << 10, 40u << 10, 80u << 10, 160u << 10, 0xFFFFFFFFu};
+                const bool force_global = std::getenv("LRSC_MSA_FORCE_GLOBAL") != nullptr;     // test hook for the global-workspace variant
+                uint32_t lo = 0;
+                for(uint32_t bk : kBuckets) {
+                    if(force_global && bk != 0xFFFFFFFFu) continue;
+                    list.clear();
+                    uint32_t need_max = 0;
+                    for(uint32_t i : todo) {
+                        const DpRequest& r = reqs[begin + i];
+                        const uint32_t need = dp_msa_lds_bytes(r.w_cols, r.str_cap, r.ops_cap, r.coverage);
+                        if(need > lo && need <= bk) { list.push_back(i); need_max = std::max(need_max, need); }
+                    }
+                    lo = bk;
+                    if(list.empty()) continue;
+                    HIP_TRY(hipMemcpyAsync(d_list.p, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+                    DpPipeArgs c2 = c;
+                    c2.req_list = d_list.p; c2.n_list = (uint32_t)list.size(); c2.lds_bytes = (need_max + 15) & ~15u;
+                    if(bk == 0xFFFFFFFFu) {
+                        HIP_TRY(d_msa_ws.reserve((uint64_t)c2.lds_bytes * dp_msa_waves(c2, true)));
+                        c2.msa_ws = d_msa_ws.p;
+                    }
+                    st = timed_launch(ctx, LRSC_K_MSA, [&]() { return launch_dp_msa(c2, ctx->stream); });
+                    if(st != LRSC_OK) return st;
+                }
                 HIP_TRY(hipMemcpy(mo.data(), d_msa.p + begin, (size_t)nc * sizeof(DpMsaOut), hipMemcpyDeviceToHost));
-                redo.clear();
-                uint32_t lds2 = 0;
-                for(uint32_t i = 0; i < nc; ++i) {
+                list.clear();
+                for(uint32_t i : todo) {
                     if(mo[i].error == 2) return fail(LRSC_ERR_LIMIT, "msa: consensus longer than 2 x query + 128");
                     if(mo[i].error != 1) continue;
                     DpRequest& r = reqs[begin + i];
+                    if(r.w_cols > 64u * (r.lq + 128)) return fail(LRSC_ERR_LIMIT, "msa: a multiple alignment needs more than 64 x its query in columns");
                     r.w_cols *= 2;
-                    const uint32_t need = dp_msa_lds_bytes(r.w_cols, r.str_cap, r.ops_cap, r.coverage);
-                    if(need > 160 * 1024) return fail(LRSC_ERR_LIMIT, "msa: the multiple alignment of a DP fallback needs more columns than fit the 160 KB LDS");
-                    lds2 = std::max(lds2, need);
-                    redo.push_back(i);
+                    list.push_back(i);
                 }
-                if(redo.empty()) break;
-                HIP_TRY(d_redo.reserve(redo.size()));
-                HIP_TRY(hipMemcpyAsync(d_reqs.p + begin, reqs.data() + begin, (size_t)nc * sizeof(DpRequest), hipMemcpyHostToDevice, ctx->stream));
-                HIP_TRY(hipMemcpyAsync(d_redo.p, redo.data(), redo.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-                DpPipeArgs c2 = c;
-                c2.req_list = d_redo.p; c2.n_list = (uint32_t)redo.size(); c2.lds_bytes = lds2;
-                st = timed_launch(ctx, LRSC_K_MSA, [&]() { return launch_dp_msa(c2, ctx->stream); });
-                if(st != LRSC_OK) return st;
+                todo = list;
+                if(!todo.empty())
+                    HIP_TRY(hipMemcpyAsync(d_reqs.p + begin, reqs.data() + begin, (size_t)nc * sizeof(DpRequest), hipMemcpyHostToDevice, ctx->stream));
             }
             n_strings += jobs;
             begin = end;
@@ -1285,7 +1302,14 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
     a.pb_coverage = (uint64_t)p.pb_coverage; a.pacbio_error_rate = p.error_rate;
     a.freqs_of_kmer_size = d_freqs.p;
     a.ctr = ctx->d_ctr;
-    a.reads_per_wave = 16;
+    // the kernel holds 2 wavefronts per SIMD (216 VGPRs): spread the reads over all of them before doubling up lanes
+    {
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+        const uint32_t resident = (uint32_t)cus * 4u * 2u;
+        a.reads_per_wave = 4;
+        while(a.reads_per_wave < 64 && (n + a.reads_per_wave - 1) / a.reads_per_wave > resident) a.reads_per_wave *= 2;
+    }
     if(const char* e = std::getenv("LRSC_READS_PER_WAVE")) {
         const int v = std::atoi(e);
         if(v >= 1 && v <= 64 && (v & (v - 1)) == 0) a.reads_per_wave = (uint32_t)v;

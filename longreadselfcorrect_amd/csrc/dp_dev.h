@@ -66,8 +66,9 @@ struct DpPipeArgs {
     uint8_t* cons;
     DpMsaOut* msa;
     uint32_t lds_bytes;           // dynamic LDS of the MSA kernel (sized for the largest request)
-    const uint32_t* req_list;     // optional: run the MSA kernel for these n_list requests only (overflow retries)
+    const uint32_t* req_list;     // optional: run the MSA kernel for these n_list requests only (size buckets, overflow retries)
     uint32_t n_list;
+    uint8_t* msa_ws;              // set: state in this global workspace (lds_bytes per workgroup) instead of LDS
     DevCounters* ctr;
 };
 
@@ -96,6 +97,8 @@ hipError_t launch_dp_retrieve(const FmIndexDev& fm, const DpPipeArgs& a, hipStre
 hipError_t launch_dp_msa(const DpPipeArgs& a, hipStream_t stream);
 uint32_t dp_msa_lds_bytes(uint32_t w_cols, uint32_t str_cap, uint32_t ops_cap, uint32_t coverage);
 // initial column capacity of one multiple alignment: the query plus the gap columns insertions may open
-constexpr uint32_t dp_msa_columns(uint32_t lq) { return 2 * lq + 128; }
+constexpr uint32_t dp_msa_columns(uint32_t lq) { return 3 * lq + 128; }
+constexpr uint32_t dp_cons_capacity(uint32_t lq) { return 2 * lq + 128; }
+uint32_t dp_msa_waves(const DpPipeArgs& a, bool global);
 
 } // namespace lrsc

@@ -42,9 +42,13 @@ uint32_t dp_msa_lds_bytes(uint32_t w_cols, uint32_t str_cap, uint32_t ops_cap, u
     return o;
 }
 
+// GLOBAL = false: state in LDS (dynamic, a.lds_bytes); true: in a global workspace slot per workgroup, for the few
+// pile-ups too wide for 160 KB.
+template <bool GLOBAL>
 __global__ __launch_bounds__(64) void dp_msa_kernel(DpPipeArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_lds[];
+    uint8_t* smem = GLOBAL ? a.msa_ws + (uint64_t)blockIdx.x * a.lds_bytes : smem_lds;
     const uint32_t lane = lane_id();
     const uint32_t n_work = a.req_list ? a.n_list : a.n_reqs;
     for(uint32_t wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
@@ -216,25 +220,33 @@ __global__ __launch_bounds__(64) void dp_msa_kernel(DpPipeArgs a)
     }
 }
 
-hipError_t launch_dp_msa(const DpPipeArgs& a, hipStream_t stream)
+uint32_t dp_msa_waves(const DpPipeArgs& a, bool global)
 {
-    if(a.n_reqs == 0) return hipSuccess;
-    if(a.lds_bytes > 160 * 1024) return hipErrorInvalidValue;
-    if(a.lds_bytes > 64 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dp_msa_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                 (int)a.lds_bytes);
-        if(e != hipSuccess) return e;
-    }
     int cus = 256, dev = 0;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    uint32_t per_cu = a.lds_bytes ? (160u * 1024u) / a.lds_bytes : 16u;
+    uint32_t per_cu = global ? 8u : (a.lds_bytes ? (160u * 1024u) / a.lds_bytes : 16u);
     per_cu = per_cu < 1 ? 1 : per_cu > 16 ? 16 : per_cu;
     uint32_t n_waves = (uint32_t)cus * per_cu;
     const uint32_t n_work = a.req_list ? a.n_list : a.n_reqs;
+    return n_waves > n_work ? n_work : n_waves;
+}
+
+hipError_t launch_dp_msa(const DpPipeArgs& a, hipStream_t stream)
+{
+    const uint32_t n_work = a.req_list ? a.n_list : a.n_reqs;
     if(n_work == 0) return hipSuccess;
-    if(n_waves > n_work) n_waves = n_work;
-    hipLaunchKernelGGL(dp_msa_kernel, dim3(n_waves), dim3(64), a.lds_bytes, stream, a);
+    if(a.msa_ws) {                                            // global-workspace variant: a.lds_bytes = bytes per workgroup slot
+        hipLaunchKernelGGL(dp_msa_kernel<true>, dim3(dp_msa_waves(a, true)), dim3(64), 0, stream, a);
+        return hipGetLastError();
+    }
+    if(a.lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+    if(a.lds_bytes > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dp_msa_kernel<false>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)a.lds_bytes);
+        if(e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(dp_msa_kernel<false>, dim3(dp_msa_waves(a, false)), dim3(64), a.lds_bytes, stream, a);
     return hipGetLastError();
 }
 

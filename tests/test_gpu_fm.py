@@ -514,10 +514,12 @@ def _dp_queries(rng, ds, n):
     return out
 
 
-@pytest.mark.parametrize("cov", [90, 20])
-def test_dp_consensus_matches_oracle(api, gpu_index, oracle, small_ds, cov):
+@pytest.mark.parametrize("cov,force_global", [(90, False), (20, False), (90, True)])
+def test_dp_consensus_matches_oracle(api, gpu_index, oracle, small_ds, cov, force_global, monkeypatch):
     """retrieveStr + extendMatch + MultipleAlignment + calculateBaseConsensus: rows, retrieved-string count and the
     consensus string, bit-identical to the oracle's line-by-line restatement of LongReadOverlap.cpp / multiple_alignment.cpp."""
+    if force_global:
+        monkeypatch.setenv("LRSC_MSA_FORCE_GLOBAL", "1")       # the pile-up state in global memory instead of LDS (very wide pile-ups)
     rng = np.random.default_rng(1234 + cov)
     qs = _dp_queries(rng, small_ds, 60)
     p = api.params_default(5, cov)
