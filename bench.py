@@ -47,6 +47,9 @@ def main():
     ap.add_argument("--reads", type=int, default=100_000, help="reads per GPU (= index reads on rank 0)")
     ap.add_argument("--read-len", type=int, default=10_000)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 disables)")
+    ap.add_argument("--stage", choices=["seeds", "correct-nodp", "correct"], default="seeds",
+                    help="seeds: BASELINE configs[1] (Occ-rank + LongReadProbe kernels, the default and the graded line); "
+                         "correct-nodp / correct: configs[2], the whole per-read path on the device without / with the DP fallback")
     args = ap.parse_args()
 
     import torch
@@ -66,7 +69,7 @@ def main():
 
     from longreadselfcorrect_amd import Lrsc
     from longreadselfcorrect_amd import dist as lrdist
-    from longreadselfcorrect_amd.capi import K_GRID, K_SEEDS
+    from longreadselfcorrect_amd.capi import K_GRID, K_SEEDS, K_EXTEND, K_LF, K_DP, K_MSA
 
     api = Lrsc()
     genome_len = int(args.genome_mb * 1e6)
@@ -88,6 +91,7 @@ def main():
     log(f"rank-block image built + uploaded in {time.time() - t:.1f}s: {info.device_bytes / 1e9:.2f} GB in HBM, "
         f"{info.block_symbols} symbols per {info.block_bytes}-byte block")
     params = api.params_default(5, 90)          # -g 5 -c 90: k = 17, pool {5,9,15,17,19}
+    params.no_dp = 1 if args.stage == "correct-nodp" else 0
     ctx = index.ctx(params, local_rank)
 
     if rank == 0:
@@ -99,8 +103,13 @@ def main():
     my_bases = int(off[-1])
     log(f"batch resident in HBM: {my_bases / 1e6:.1f} Mbases")
 
+    fm_walks = [0, 0, 0]
+
     def step():
         batch.find_seeds()      # k-mer grid (Occ-rank kernel) + getSeqAttribute + greedy seed scan, all on the device
+        if args.stage != "seeds":
+            res, _, _ = batch.correct()      # chain of seed-to-seed FM-extensions (+ DP/MSA rounds) and stitching, on the device
+            fm_walks[0] = sum(r.total_walk_num for r in res); fm_walks[1] = sum(r.fm_num for r in res); fm_walks[2] = sum(r.dp_num for r in res)
 
     for _ in range(args.warmup):
         step()
@@ -154,12 +163,18 @@ def main():
             "dtype": "int64",
             "data": "synthetic",
             "config": {
-                "workload": (f"BASELINE configs[1]: {n_reads} x {args.read_len / 1000:g} kb reads/GPU (15% err: 4.5% del, 1.5% sub, 9% ins) "
+                "workload": (f"BASELINE configs[{1 if args.stage == 'seeds' else 2}]: {n_reads} x {args.read_len / 1000:g} kb reads/GPU (15% err: 4.5% del, 1.5% sub, 9% ins) "
                              f"over the FM-index of the {n_reads}-read 90x set of a {args.genome_mb:g} Mb genome "
                              f"({n_sym / 1e9:.2f} G symbols/strand), -c 90 -g 5"),
                 "stages_timed": ["LongReadProbe k-mer feature grid (Occ-rank kernel)",
                                  "getSeqAttribute + searchSeedsWithHybridKmers + estimateBestKmerSize + removeHitchhikingSeeds"],
-                "stage_ms": {"kmer_grid": kernel_ms, "seed_scan_group": st_seeds.total_ms / max(st_seeds.launches, 1)},
+                "stage_ms": {"kmer_grid": kernel_ms, "seed_scan_group": st_seeds.total_ms / max(st_seeds.launches, 1),
+                             **({} if args.stage == "seeds" else {
+                                 "fm_extend_and_stitch": ctx.stats(K_EXTEND).total_ms / args.steps,
+                                 "dp_retrieve_lf_walks": ctx.stats(K_LF).total_ms / args.steps,
+                                 "dp_extend_match": ctx.stats(K_DP).total_ms / args.steps,
+                                 "dp_msa_consensus": ctx.stats(K_MSA).total_ms / args.steps})},
+                **({} if args.stage == "seeds" else {"stage": args.stage, "walks_per_step": fm_walks[0], "fm_walks": fm_walks[1], "dp_walks": fm_walks[2]}),
                 "index_hbm_gb": info.device_bytes / 1e9,
                 "reads_per_gpu": n_reads,
                 "parallelism": f"reads sharded x{world}, index replicated, no data-path collective",
@@ -182,7 +197,7 @@ def main():
             },
         }
         if world == 1 and args.cpu_seconds > 0:
-            result["cpu_baseline"] = cpu_baseline(units, n_reads, n_sym, params, bases, off, args.cpu_seconds)
+            result["cpu_baseline"] = cpu_baseline(units, n_reads, n_sym, params, bases, off, args.cpu_seconds, args.stage)
         print(json.dumps(result), flush=True)
 
     batch.close()
@@ -192,8 +207,8 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(units, n_reads, n_sym, params, bases, off, budget_s):
-    """The CPU oracle (port of the reference's LongReadProbe seed finder) on a bounded sample of the same reads."""
+def cpu_baseline(units, n_reads, n_sym, params, bases, off, budget_s, stage="seeds"):
+    """The CPU oracle (port of the reference's path for the same stages) on a bounded sample of the same reads."""
     from oracle import oracle_py
 
     log("cpu_baseline: loading the index into the CPU oracle (RLBWT markers)")
@@ -201,6 +216,20 @@ def cpu_baseline(units, n_reads, n_sym, params, bases, off, budget_s):
     ob = orc.bwt_from_units(units[0], n_reads, n_sym)
     orb = orc.bwt_from_units(units[1], n_reads, n_sym)
     ks = np.array([5, 9, 15, 17, 19], dtype=np.uint8)
+    if stage != "seeds":
+        t = time.perf_counter()
+        orc.correct_reads(ob, orb, params, bases[: int(off[2])], off[:3].copy()).close()
+        per_read = (time.perf_counter() - t) / 2
+        n = int(max(2, min(len(off) - 1, budget_s / max(per_read, 1e-6))))
+        log(f"cpu_baseline: {per_read * 1e3:.0f} ms/read -> sampling {n} reads")
+        t = time.perf_counter()
+        run = orc.correct_reads(ob, orb, params, bases[: int(off[n])], off[: n + 1].copy())
+        dt = time.perf_counter() - t
+        walks = int(run.counters[:, 3].sum())
+        run.close()
+        return {"value": int(off[n]) / dt / 1e6, "unit": "Mbases/s", "cores": 1, "kind": "port",
+                "sample": f"first {n} reads ({int(off[n]) / 1e6:.2f} Mbases, {walks} walks) of the same batch, whole per-read path "
+                          f"(PacBioSelfCorrectionProcess::process, no_dp={params.no_dp}), oracle/ restatement, 1 thread, {dt:.1f}s"}
     # calibrate on 2 reads, then size the sample to the budget
     t = time.perf_counter()
     orc.find_seeds(ob, orb, params, bases[: int(off[2])], off[:3].copy())

@@ -182,6 +182,8 @@ class Lrsc:
                                     C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         L.lrsc_dp_consensus.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64,
                                         C.POINTER(C.c_uint64)]
+        L.lrsc_batch_correct.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                         C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.lrsc_batch_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
         L.lrsc_batch_destroy.argtypes = [C.c_void_p]
         L.lrsc_batch_destroy.restype = None
@@ -516,6 +518,25 @@ class Batch:
                 continue
             api.check(st, "lrsc_batch_seeds")
             return count, seeds[: n.value].copy(), attr
+
+    def correct(self):
+        """lrsc_batch_correct on the resident batch -> (results ReadResult[n], piece offsets uint64[], corrected bytes uint8[])."""
+        api = self.ctx.api
+        n = self.n_reads
+        res = (ReadResult * n)()
+        if not hasattr(self, "_poff"):
+            self._poff = np.zeros(2 * n + 17, dtype=np.uint64)
+            self._out = np.zeros(self.total_bases * 2 + 4096, dtype=np.uint8)
+        npieces, used = C.c_uint64(), C.c_uint64()
+        while True:
+            st = api.lib.lrsc_batch_correct(self.ctx.h, self.h, res, _ptr(self._poff), self._poff.size, _ptr(self._out), self._out.size,
+                                            C.byref(npieces), C.byref(used))
+            if st == -6 and (int(npieces.value) + 1 > self._poff.size or int(used.value) > self._out.size):
+                self._poff = np.zeros(max(self._poff.size, int(npieces.value) + 1), dtype=np.uint64)
+                self._out = np.zeros(max(self._out.size, int(used.value)), dtype=np.uint8)
+                continue
+            api.check(st, "lrsc_batch_correct")
+            return res, self._poff[: int(npieces.value) + 1], self._out[: int(used.value)]
 
     def close(self):
         if self.h:
