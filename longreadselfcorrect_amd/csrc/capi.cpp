@@ -54,7 +54,7 @@ static int hip_fail(hipError_t e, const char* what)
 struct DeviceCopy {
     void* blocks[2] = {nullptr, nullptr};
     uint64_t* dollars[2] = {nullptr, nullptr};
-    void* ktab[3] = {nullptr, nullptr, nullptr};
+    void* ktab[4] = {nullptr, nullptr, nullptr, nullptr};
     FmIndexDev dev{};
 };
 
@@ -275,24 +275,36 @@ extern "C" int lrsc_index_upload(lrsc_index* idx, int device)
         fs.n_blocks = im.n_blocks;
         for(int c = 0; c < 5; ++c) fs.pred[c] = im.pred[c];
     }
-    // k-mer interval tables (narrow indexes): sizes 5 and 9 (the walk's 5-mer / idmer look-ups) and
-    // T = floor(log4 N) clamped to [9, 13] (16 bytes x 4^T: 1.07 GB at T = 13); LRSC_KTAB_K overrides T, 0 disables.
+    // k-mer interval tables (narrow indexes): sizes 5 and 9 (the walk's 5-mer / idmer look-ups), T = floor(log4 N) clamped
+    // to [9, 13] -- up to there practically every k-mer occurs in the index -- and T + 2, where most chance matches have
+    // died (16 bytes x 4^k: 1.07 GB at 13, 17.2 GB at 15, taken only if it fits a quarter of the free HBM).
+    // LRSC_KTAB_K overrides T (0 disables all tables), LRSC_KTAB_K2 the fourth size (0 disables it).
     if(!idx->wide) {
         int T = 0;
         for(uint64_t n = idx->num_symbols; n >= 4; n >>= 2) ++T;
         T = std::max(9, std::min(13, T));
         if(const char* e = std::getenv("LRSC_KTAB_K")) T = std::atoi(e);
-        uint32_t ks[3] = {5, 9, (uint32_t)T};
+        int T2 = T > 0 ? std::min(15, T + 2) : 0;
+        if(const char* e = std::getenv("LRSC_KTAB_K2")) T2 = std::atoi(e);
+        uint32_t want[4] = {5, 9, (uint32_t)T, (uint32_t)T2};
+        uint32_t ks[4] = {0, 0, 0, 0};
         uint32_t n_t = 0;
-        for(int i = 0; i < 3 && T > 0; ++i) {
-            if(ks[i] == 0 || ks[i] > 14 || (i > 0 && ks[i] <= ks[i - 1])) continue;
-            const size_t bytes = (size_t)16 << (2 * ks[i]);
+        for(int i = 0; i < 4 && T > 0; ++i) {
+            if(want[i] == 0 || want[i] > 15 || (n_t > 0 && want[i] <= ks[n_t - 1])) continue;
+            const size_t bytes = (size_t)16 << (2 * want[i]);
+            if(i == 3) {
+                size_t free_b = 0, total_b = 0;
+                HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+                if(bytes > free_b / 4) continue;
+            }
             HIP_TRY(hipMalloc(&dc.ktab[n_t], bytes));
-            hipError_t e2 = launch_ktab_build(dc.dev, ks[i], dc.ktab[n_t], nullptr);
+            // each table starts from the previous (smaller) one; dc.dev.ktab[].k stays 0 until all are built so that the
+            // builder's own walk_step never consults a table
+            hipError_t e2 = launch_ktab_build(dc.dev, want[i], dc.ktab[n_t], n_t ? ks[n_t - 1] : 0, n_t ? dc.ktab[n_t - 1] : nullptr, nullptr);
             if(e2 != hipSuccess) return hip_fail(e2, "ktab build");
             dc.dev.ktab[n_t].entries = dc.ktab[n_t];
-            dc.dev.ktab[n_t].k = 0;            // tables become visible only once all are built (the builder must not use them)
-            ks[n_t] = ks[i];
+            dc.dev.ktab[n_t].k = 0;
+            ks[n_t] = want[i];
             ++n_t;
         }
         HIP_TRY(hipDeviceSynchronize());
@@ -311,7 +323,7 @@ extern "C" void lrsc_index_close(lrsc_index* idx)
             if(kv.second.blocks[s]) (void)hipFree(kv.second.blocks[s]);
             if(kv.second.dollars[s]) (void)hipFree(kv.second.dollars[s]);
         }
-        for(int t = 0; t < 3; ++t) if(kv.second.ktab[t]) (void)hipFree(kv.second.ktab[t]);
+        for(int t = 0; t < 4; ++t) if(kv.second.ktab[t]) (void)hipFree(kv.second.ktab[t]);
     }
     delete idx;
 }

@@ -79,7 +79,7 @@ hipError_t launch_seed_scan(const FmIndexDev& fm, const SeedArgs& a, uint32_t mi
 hipError_t scan_seed_flags(unsigned long long* flags, uint32_t* zeros, uint64_t n, void** tmp, size_t* tmp_cap, hipStream_t stream);
 
 // fills a k-mer interval table (4^k uint4 entries) by running the k-step findBiInterval of every k-mer
-hipError_t launch_ktab_build(const FmIndexDev& fm, uint32_t k, void* entries, hipStream_t stream);
+hipError_t launch_ktab_build(const FmIndexDev& fm, uint32_t k, void* entries, uint32_t prev_k, const void* prev, hipStream_t stream);
 hipError_t launch_rank(const FmIndexDev& fm, const lrsc_rank_query* q, uint64_t n, uint64_t* out,
                        DevCounters* ctr, hipStream_t stream);
 // LF-walk (LongReadOverlap::retrieveStr, PacBio/LongReadOverlap.cpp:696-749): from BWT row `row` of `strand`,

@@ -180,20 +180,30 @@ __global__ __launch_bounds__(256) void kmer_grid_kernel(FmIndexDev fm, GridArgs 
             if(a.slot_iv) a.slot_iv[(uint64_t)j * a.total_bases + gid] = to_out(st.fwd, st.rvc);
         };
 
-        // Compact mode: only frequency / validity / the base-search counter are emitted, so the first T steps
-        // can come from the k-mer table when both strands are still valid after them (then no early exit
-        // happened, the chained expand() state equals the plain search, and the base counter is base_k).
+        // Compact mode: only frequency / validity / the base-search counter are emitted.  An empty interval stays empty
+        // under updateInterval (Occ(c, lo-1) == Occ(c, hi) when hi == lo-1) and contributes frequency 0, so (a) the table
+        // entry -- findInterval semantics, a strand frozen at its first empty interval -- is as good as the reference's
+        // chained expand() state whenever the 5-mer base search itself ran to the end on the fwd strand (then the base
+        // counter is base_k), and (b) a strand that went empty needs no further Occ queries at all.
         uint32_t s0 = 0;
+        bool lean = false;
         if(!WIDE && !a.out_iv && !a.out_size && !a.out_count && !a.slot_iv) {
             WalkState<P> ts = st;
             const uint32_t tk = table_start<WIDE>(fm, [&](uint32_t t) { return (uint32_t)w[t]; }, avail, ts);
-            if(tk >= base_k && !ts.fwd_broken && !ts.rvc_broken) {
+            if(tk >= base_k) {
+                bool fwd_base_ok = !ts.fwd_broken;              // valid after tk >= base_k steps => valid after base_k
+                if(!fwd_base_ok && tk > base_k) {
+                    WalkState<P> tb = st;
+                    const uint32_t kb = table_start<WIDE>(fm, [&](uint32_t t) { return (uint32_t)w[t]; }, base_k, tb);
+                    fwd_base_ok = kb == base_k && !tb.fwd_broken;
+                    n_tab += kb != 0;
+                }
                 // slots below the table size are not stored in compact mode (freq_index < 0): check, else fall back
-                bool ok = true;
+                bool ok = fwd_base_ok;
                 for(uint32_t j = 0; j < a.n_k && a.ks[j] < tk; ++j) ok = ok && (a.freq_index[j] < 0);
                 if(ok) {
                     st = ts; st.counted = base_k; st.n_rank = 0; st.n_blk = 0;
-                    s0 = tk; n_tab = 1;
+                    s0 = tk; n_tab += 1; lean = true;
                     while(slot < a.n_k && a.ks[slot] < tk) ++slot;
                     next_k = slot < a.n_k ? a.ks[slot] : 0xFFFFFFFFu;
                     if(st.size == next_k) { emit(slot); ++slot; next_k = slot < a.n_k ? a.ks[slot] : 0xFFFFFFFFu; }
@@ -201,7 +211,21 @@ __global__ __launch_bounds__(256) void kmer_grid_kernel(FmIndexDev fm, GridArgs 
             }
         }
         for(uint32_t s = s0; s < avail; ++s) {
-            st = walk_step<WIDE>(sf, sr, w[s], base_k, st, mtab);
+            if(lean) {
+                const uint32_t c = w[s];
+                if(!st.fwd_broken) {
+                    st.fwd = update_interval<WIDE>(sf, c, st.fwd, mtab, st.n_blk);
+                    st.fwd_broken = st.fwd.lo > st.fwd.hi;
+                    st.n_rank += 2;
+                }
+                if(!st.rvc_broken) {
+                    st.rvc = update_interval<WIDE>(sr, 3u - c, st.rvc, mtab, st.n_blk);
+                    st.rvc_broken = st.rvc.lo > st.rvc.hi;
+                    st.n_rank += 2;
+                }
+                ++st.size;
+            } else
+                st = walk_step<WIDE>(sf, sr, w[s], base_k, st, mtab);
             if(st.size == next_k) {
                 emit(slot);
                 ++slot;
@@ -217,8 +241,10 @@ __global__ __launch_bounds__(256) void kmer_grid_kernel(FmIndexDev fm, GridArgs 
     flush_counters(ctr, n_rank, n_blk, n_tab);
 }
 
-// every k-mer's findBiInterval (with early exit) -> table entry; narrow layout only
-__global__ __launch_bounds__(256) void ktab_build_kernel(FmIndexDev fm, uint32_t k, uint4* __restrict__ entries)
+// every k-mer's findBiInterval (with early exit) -> table entry; narrow layout only.  A smaller table that is already
+// built (prev_k < k) supplies the state after the first prev_k characters.
+__global__ __launch_bounds__(256) void ktab_build_kernel(FmIndexDev fm, uint32_t k, uint4* __restrict__ entries, uint32_t prev_k,
+                                                         const uint4* __restrict__ prev)
 {
     using P = uint32_t;
     __shared__ __attribute__((aligned(16))) uint32_t mtab[MaskTabSize<false>::value];
@@ -228,7 +254,13 @@ __global__ __launch_bounds__(256) void ktab_build_kernel(FmIndexDev fm, uint32_t
     const StrandC<P> sf = strand_consts<P>(fm.strand[LRSC_RBWT]);
     const StrandC<P> sr = strand_consts<P>(fm.strand[LRSC_BWT]);
     WalkState<P> st = walk_init<P>();
-    for(uint32_t t = 0; t < k; ++t) {
+    if(prev_k != 0) {
+        const uint4 e = prev[code >> (2 * (k - prev_k))];
+        st.fwd.lo = e.x; st.fwd.hi = e.y; st.rvc.lo = e.z; st.rvc.hi = e.w;
+        st.fwd_broken = e.x > e.y; st.rvc_broken = e.z > e.w;
+        st.size = prev_k;
+    }
+    for(uint32_t t = prev_k; t < k; ++t) {
         if(st.fwd_broken && st.rvc_broken) break;
         const uint32_t c = (uint32_t)(code >> (2 * (k - 1 - t))) & 3u;
         st = walk_step<false>(sf, sr, c, 1u << 30, st, mtab);
@@ -313,11 +345,12 @@ hipError_t launch_kmer_grid(const FmIndexDev& fm, const GridArgs& a, DevCounters
     return hipGetLastError();
 }
 
-hipError_t launch_ktab_build(const FmIndexDev& fm, uint32_t k, void* entries, hipStream_t stream)
+hipError_t launch_ktab_build(const FmIndexDev& fm, uint32_t k, void* entries, uint32_t prev_k, const void* prev, hipStream_t stream)
 {
-    if(fm.wide || k == 0 || k > 15) return hipErrorInvalidValue;
+    if(fm.wide || k == 0 || k > 15 || prev_k >= k) return hipErrorInvalidValue;
     const uint64_t n = 1ull << (2 * k);
-    hipLaunchKernelGGL(ktab_build_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, fm, k, reinterpret_cast<uint4*>(entries));
+    hipLaunchKernelGGL(ktab_build_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, fm, k, reinterpret_cast<uint4*>(entries), prev_k,
+                       reinterpret_cast<const uint4*>(prev));
     return hipGetLastError();
 }
 
