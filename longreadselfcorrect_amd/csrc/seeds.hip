@@ -129,17 +129,38 @@ __device__ __forceinline__ uint64_t next_start(const unsigned long long* __restr
 // find `k` characters starting at codes[start], moving by `step`, optionally complemented, with
 // findInterval's early exit (BWTAlgorithms.cpp:14-31).  Returns the clamped frequency.
 template <bool WIDE>
-__device__ __forceinline__ int64_t find_run(const StrandC<typename Lay<WIDE>::pos_t>& s, const uint8_t* __restrict__ codes,
-                                            int64_t start, int step, int k, bool comp, const uint32_t* __restrict__ mtab,
-                                            uint32_t& n_rank, uint32_t& n_blk)
+__device__ __forceinline__ int64_t find_run(const FmIndexDev& fm, bool on_bwt, const StrandC<typename Lay<WIDE>::pos_t>& s,
+                                            const uint8_t* __restrict__ codes, int64_t start, int step, int k, bool comp,
+                                            const uint32_t* __restrict__ mtab, uint32_t& n_rank, uint32_t& n_blk)
 {
     using P = typename Lay<WIDE>::pos_t;
-    uint32_t c = codes[start];
-    if(comp) c = 3u - c;
-    IvT<P> iv = init_interval<P>(s, c);
-    n_rank += 1;
-    for(int j = 1; j < k; ++j) {
-        c = codes[start + (int64_t)j * step];
+    // The characters are consumed in the order c_0, c_1, ...  On the rBWT that is the table's fwd walk of w = c; on the BWT
+    // it is the rvc walk of w = complement(c): the first T of them come from the k-mer table (frozen at the first empty
+    // interval, like the loop below).
+    IvT<P> iv;
+    int j0 = 0;
+    {
+        WalkState<P> ts = walk_init<P>();
+        const uint32_t tk = table_start<WIDE>(fm, [&](uint32_t t) {
+            uint32_t c = codes[start + (int64_t)t * step];
+            if(comp) c = 3u - c;
+            return on_bwt ? 3u - c : c; }, (uint32_t)k, ts);
+        if(tk != 0) {
+            iv = on_bwt ? ts.rvc : ts.fwd;
+            n_rank += 1;
+            if(iv.lo > iv.hi) return 0;
+            j0 = (int)tk;
+        }
+    }
+    if(j0 == 0) {
+        uint32_t c = codes[start];
+        if(comp) c = 3u - c;
+        iv = init_interval<P>(s, c);
+        n_rank += 1;
+        j0 = 1;
+    }
+    for(int j = j0; j < k; ++j) {
+        uint32_t c = codes[start + (int64_t)j * step];
         if(comp) c = 3u - c;
         iv = update_interval<WIDE>(s, c, iv, mtab, n_blk);
         n_rank += 2;
@@ -209,7 +230,8 @@ __global__ __launch_bounds__(64) void seed_scan_kernel(FmIndexDev fm, SeedArgs a
                         if(!dyn.have_iv) {
                             // the static k-mer at seedPos passed isValid(): its chained interval equals a plain search
                             WalkState<P> st = walk_init<P>();
-                            for(int t = 0; t < dyn.size; ++t) st = walk_step<WIDE>(sF, sR, codes[seedPos + t], 1u << 30, st, mtab);
+                            const uint32_t t0 = table_start<WIDE>(fm, [&](uint32_t t) { return (uint32_t)codes[seedPos + t]; }, (uint32_t)dyn.size, st);
+                            for(int t = (int)t0; t < dyn.size; ++t) st = walk_step<WIDE>(sF, sR, codes[seedPos + t], 1u << 30, st, mtab);
                             n_rank += st.n_rank; n_blk += st.n_blk;
                             dfwd = st.fwd; drvc = st.rvc;
                             dyn.have_iv = true;
@@ -263,11 +285,11 @@ __global__ __launch_bounds__(64) void seed_scan_kernel(FmIndexDev fm, SeedArgs a
                             auto occ = [&](int k) -> int {
                                 int64_t f;
                                 if(pole) {
-                                    f = find_run<WIDE>(sel, codes, seedPos, +1, k, false, mtab, n_rank, n_blk);
-                                    f += find_run<WIDE>(sel, codes, seedPos + k - 1, -1, k, true, mtab, n_rank, n_blk);
+                                    f = find_run<WIDE>(fm, false, sel, codes, seedPos, +1, k, false, mtab, n_rank, n_blk);
+                                    f += find_run<WIDE>(fm, false, sel, codes, seedPos + k - 1, -1, k, true, mtab, n_rank, n_blk);
                                 } else {
-                                    f = find_run<WIDE>(sel, codes, seedPos + seedLen - 1, -1, k, false, mtab, n_rank, n_blk);
-                                    f += find_run<WIDE>(sel, codes, seedPos + seedLen - k, +1, k, true, mtab, n_rank, n_blk);
+                                    f = find_run<WIDE>(fm, true, sel, codes, seedPos + seedLen - 1, -1, k, false, mtab, n_rank, n_blk);
+                                    f += find_run<WIDE>(fm, true, sel, codes, seedPos + seedLen - k, +1, k, true, mtab, n_rank, n_blk);
                                 }
                                 return (int)f;
                             };
