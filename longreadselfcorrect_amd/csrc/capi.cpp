@@ -1318,7 +1318,9 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
     {
         int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
-        const uint32_t resident = (uint32_t)cus * 4u * 2u;
+        a.occupancy = 4;
+        if(const char* e = std::getenv("LRSC_CORRECT_OCC")) a.occupancy = std::atoi(e) >= 4 ? 4u : 2u;   // 8 (64 VGPRs) spills too much: 38 s vs 21 s at 100k reads
+        const uint32_t resident = (uint32_t)cus * 4u * a.occupancy;
         a.reads_per_wave = 4;
         while(a.reads_per_wave < 64 && (n + a.reads_per_wave - 1) / a.reads_per_wave > resident) a.reads_per_wave *= 2;
     }

@@ -52,6 +52,7 @@ struct CorrectArgs {
     const ReadWork* work;
     uint32_t n_reads, min_k;
     uint32_t reads_per_wave;         // 1..64, power of two: 64 / reads_per_wave lanes apart
+    uint32_t occupancy;              // wavefronts per SIMD the kernel variant is compiled for: 2 (216 VGPRs) or 4 (128, spills)
     uint8_t* workspace;
     uint8_t* out_codes;
     uint32_t* piece_start;

@@ -14,8 +14,8 @@
 
 namespace lrsc {
 
-template <bool WIDE>
-__global__ __launch_bounds__(64, 2) void correct_reads_kernel(FmIndexDev fm, CorrectArgs a)
+template <bool WIDE, int OCC>
+__global__ __launch_bounds__(64, OCC) void correct_reads_kernel(FmIndexDev fm, CorrectArgs a)
 {
     using P = typename Lay<WIDE>::pos_t;
     __shared__ __attribute__((aligned(16))) uint32_t mtab[MaskTabSize<WIDE>::value];
@@ -338,8 +338,13 @@ hipError_t launch_correct_reads(const FmIndexDev& fm, const CorrectArgs& a, hipS
     if(a.n_reads == 0) return hipSuccess;
     if(a.reads_per_wave == 0 || a.reads_per_wave > 64 || (a.reads_per_wave & (a.reads_per_wave - 1))) return hipErrorInvalidValue;
     const unsigned nb = (a.n_reads + a.reads_per_wave - 1) / a.reads_per_wave;
-    if(fm.wide) hipLaunchKernelGGL(correct_reads_kernel<true>, dim3(nb), dim3(64), 0, stream, fm, a);
-    else        hipLaunchKernelGGL(correct_reads_kernel<false>, dim3(nb), dim3(64), 0, stream, fm, a);
+    if(a.occupancy >= 4) {
+        if(fm.wide) hipLaunchKernelGGL((correct_reads_kernel<true, 4>), dim3(nb), dim3(64), 0, stream, fm, a);
+        else        hipLaunchKernelGGL((correct_reads_kernel<false, 4>), dim3(nb), dim3(64), 0, stream, fm, a);
+    } else {
+        if(fm.wide) hipLaunchKernelGGL((correct_reads_kernel<true, 2>), dim3(nb), dim3(64), 0, stream, fm, a);
+        else        hipLaunchKernelGGL((correct_reads_kernel<false, 2>), dim3(nb), dim3(64), 0, stream, fm, a);
+    }
     return hipGetLastError();
 }
 
