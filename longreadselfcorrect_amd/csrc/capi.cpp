@@ -1123,6 +1123,7 @@ struct DpStage {
         if(n == 0) return LRSC_OK;
         for(DpRequest& r : reqs) {
             if(r.k == 0 || r.lq < r.k) return fail(LRSC_ERR_ARG, "dp request: kmer_len must satisfy 1 <= kmer_len <= query length");
+            if(r.coverage > 1000) return fail(LRSC_ERR_UNSUPPORTED, "dp request: coverage above 1000 (12-bit column counters)");
             r.max_len = (uint32_t)(size_t)(r.lq * 1.1 + 20);                 // LongReadOverlap.cpp:618
             r.str_cap = (std::max(r.max_len, r.k) + 3) & ~3u;
             r.ops_cap = (r.lq + r.str_cap + 1 + 3) & ~3u;
@@ -1157,7 +1158,7 @@ struct DpStage {
                 r.job_first = jobs; r.str_off = sbytes; r.ops_off = obytes;
                 jobs += r.n_str; sbytes += sb; obytes += ob;
                 max1 = std::max(max1, r.lq); max2 = std::max(max2, r.str_cap);
-                lds = std::max(lds, dp_msa_lds_bytes(r.w_cols, r.str_cap, r.ops_cap, r.coverage));
+                lds = std::max(lds, dp_msa_lds_bytes(r.w_cols, r.str_cap, r.ops_cap, r.n_str));
                 ++end;
             }
             if(jobs >= (1ull << 32)) return fail(LRSC_ERR_UNSUPPORTED, "dp chunk: too many alignments");
@@ -1179,7 +1180,10 @@ struct DpStage {
                 al.band_width = 200; al.match_score = 1; al.gap_penalty = -1; al.mismatch_penalty = -8;   // LongReadOverlap.cpp:635-643
                 al.ops = d_ops.p; al.out = d_align.p; al.max_s1 = max1; al.max_s2 = max2; al.reqs = c.reqs;
                 al.trace_stride = (uint64_t)(max1 + 17) * kDpTraceStride;
-                const uint32_t nw = (uint32_t)std::min<uint64_t>(n_waves, jobs);
+                // 8 wavefronts per SIMD hide the scan's cross-lane latency; the traceback scratch is capped at 4 GB
+                uint64_t nw64 = std::min<uint64_t>((uint64_t)n_waves * 4, jobs);
+                nw64 = std::max<uint64_t>(1, std::min<uint64_t>(nw64, (4ull << 30) / al.trace_stride));
+                const uint32_t nw = (uint32_t)nw64;
                 HIP_TRY(d_trace.reserve(al.trace_stride * nw));
                 al.trace = d_trace.p;
                 st = timed_launch(ctx, LRSC_K_DP, [&]() { return launch_dp_align(al, nw, ctx->stream); });
@@ -1213,7 +1217,7 @@ struct DpStage {
             DevBuf<uint8_t> d_msa_ws;
             HIP_TRY(d_list.reserve(nc));
             while(!todo.empty()) {
-                static const uint32_t kBuckets[] = {16u << 10, 24u << 10, 40u << 10, 80u << 10, 160u << 10, 0xFFFFFFFFu};
+                static const uint32_t kBuckets[] = {8u << 10, 12u << 10, 16u << 10, 24u << 10, 40u << 10, 80u << 10, 160u << 10, 0xFFFFFFFFu};
                 const bool force_global = std::getenv("LRSC_MSA_FORCE_GLOBAL") != nullptr;     // test hook for the global-workspace variant
                 uint32_t lo = 0;
                 for(uint32_t bk : kBuckets) {
@@ -1222,7 +1226,7 @@ struct DpStage {
                     uint32_t need_max = 0;
                     for(uint32_t i : todo) {
                         const DpRequest& r = reqs[begin + i];
-                        const uint32_t need = dp_msa_lds_bytes(r.w_cols, r.str_cap, r.ops_cap, r.coverage);
+                        const uint32_t need = dp_msa_lds_bytes(r.w_cols, r.str_cap, r.ops_cap, r.n_str);
                         if(need > lo && need <= bk) { list.push_back(i); need_max = std::max(need_max, need); }
                     }
                     lo = bk;
@@ -1246,6 +1250,12 @@ struct DpStage {
                     if(r.w_cols > 64u * (r.lq + 128)) return fail(LRSC_ERR_LIMIT, "msa: a multiple alignment needs more than 64 x its query in columns");
                     r.w_cols *= 2;
                     list.push_back(i);
+                }
+                if(std::getenv("LRSC_CORRECT_PROFILE") && begin == 0) {
+                    double kt = 0, ks = 0, ki = 0, ni = 0, rows = 0;
+                    for(uint32_t i = 0; i < nc; ++i) { kt += mo[i].kc_total; ks += mo[i].kc_stage; ki += mo[i].kc_insert; ni += mo[i].n_insert; rows += mo[i].n_rows; }
+                    std::fprintf(stderr, "[lrsc] msa: %u requests, %.1f rows avg, %.0f insertions avg, per request %.0f k-ticks (staging %.0f, insertions %.0f), redo %zu\n",
+                                 nc, rows / nc, ni / nc, kt / nc, ks / nc, ki / nc, list.size());
                 }
                 todo = list;
                 if(!todo.empty())
@@ -1395,6 +1405,10 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
     HIP_TRY(hipMemcpyAsync(d_order.p, order.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     a.workspace = d_ws.p; a.out_codes = d_codes_out.p; a.piece_start = d_pieces.p;
 
+    // With the DP fallback on, a read runs at most max_walks walks per launch: a round then lasts about as long as
+    // max_walks walks instead of as long as the luckiest read's failure-free stretch, and parked reads get their answer sooner.
+    a.max_walks = p.no_dp ? 0u : 8u;
+    if(const char* e = std::getenv("LRSC_CORRECT_MAX_WALKS")) a.max_walks = (uint32_t)std::max(0, std::atoi(e));
     int st = timed_launch(ctx, LRSC_K_EXTEND, [&]() { return launch_correct_reads(ctx->fm, a, ctx->stream); });
     if(st != LRSC_OK) return st;
 
@@ -1402,7 +1416,7 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
     //      answers all of them at once and the kernel resumes just those reads (:129-149) -------------------------------
     std::vector<ReadOut> ro(n);
     HIP_TRY(hipMemcpy(ro.data(), d_out.p, (size_t)n * sizeof(ReadOut), hipMemcpyDeviceToHost));
-    if(!p.no_dp) {
+    if(!p.no_dp || a.max_walks != 0) {
         DpStage stage;
         DevBuf<uint32_t> d_dp_index, d_parked;
         std::vector<uint32_t> parked, dp_index(n, 0);
@@ -1414,7 +1428,9 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
             for(uint32_t i = 0; i < n; ++i) {
                 const uint32_t r = order[i];                    // keep the long-reads-first order
                 const ReadOut& o = ro[r];
-                if(o.error != 0 || o.state != kReadParked) continue;
+                if(o.error != 0 || o.state == kReadDone) continue;
+                parked.push_back(r);
+                if(o.state != kReadParked) continue;            // yielded: just goes on in the next launch
                 DpRequest q;
                 std::memset(&q, 0, sizeof(q));
                 q.q_off = work[r].ws_off + work[r].o_dpq;
@@ -1431,7 +1447,6 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
                 q.min_identity = identity; q.min_call_coverage = (int32_t)min_call_coverage;
                 dp_index[r] = (uint32_t)reqs.size();
                 reqs.push_back(q);
-                parked.push_back(r);
             }
             if(parked.empty()) break;
             st = stage.run(ctx, d_ws.p, reqs);
@@ -1445,8 +1460,8 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
             if(st != LRSC_OK) return st;
             HIP_TRY(hipMemcpy(ro.data(), d_out.p, (size_t)n * sizeof(ReadOut), hipMemcpyDeviceToHost));
             if(std::getenv("LRSC_CORRECT_PROFILE"))
-                std::fprintf(stderr, "[lrsc] DP round %u: %zu reads parked, %llu strings aligned\n", round, parked.size(),
-                             (unsigned long long)stage.n_strings);
+                std::fprintf(stderr, "[lrsc] DP round %u: %zu reads in flight, %zu DP requests, %llu strings aligned\n", round, parked.size(),
+                             reqs.size(), (unsigned long long)stage.n_strings);
         }
     }
     a.n_reads = n;

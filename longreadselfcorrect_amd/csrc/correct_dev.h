@@ -9,7 +9,8 @@
 namespace lrsc {
 
 enum { LRSC_WALK_ERR_GEOMETRY = -103, LRSC_WALK_ERR_OUTPUT = -104, LRSC_WALK_ERR_CODE = -105, LRSC_WALK_ERR_DP = -106 };
-enum : uint32_t { kReadDone = 0, kReadParked = 1 };   // ReadOut::state: parked = waiting for the DP stage's answer
+enum : uint32_t { kReadDone = 0, kReadParked = 1, kReadYield = 2 };   // ReadOut::state: parked = waiting for the DP stage's
+                                                                        // answer; yield = walk budget of this launch used up
 
 constexpr uint32_t kMaxInitK = 59;       // initk + 2 = maxOverlap must stay below the 64-character suffix window
 
@@ -63,6 +64,7 @@ struct CorrectArgs {
     int32_t start_kmer_len, next_target, split, no_dp;
     // second and later launches: reads parked on a DP request pick up the answer
     uint32_t resume;
+    uint32_t max_walks;              // walks a read may run per launch before it yields (0 = no limit); keeps DP rounds even
     const uint32_t* dp_index;        // read -> request
     const DpRequest* dp_reqs;
     const DpMsaOut* dp_msa;

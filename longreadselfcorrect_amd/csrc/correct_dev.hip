@@ -49,7 +49,7 @@ __global__ __launch_bounds__(64, OCC) void correct_reads_kernel(FmIndexDev fm, C
             cyc_prep = R.cyc[0];
         } else { R.cyc[0] = 0; R.cyc[1] = 0; R.cyc[2] = 0; R.cyc[3] = 0; R.steps = 0; }
 
-        if(n_seeds >= 2 && !(resume && R.state != kReadParked)) {
+        if(n_seeds >= 2 && !(resume && R.state == kReadDone)) {
             uint8_t* ws = a.workspace + rw.ws_off;
             Walk<WIDE> W;
             W.sF = strand_consts<P>(fm.strand[LRSC_RBWT]);
@@ -95,6 +95,9 @@ __global__ __launch_bounds__(64, OCC) void correct_reads_kernel(FmIndexDev fm, C
                 S_seedLen = seeds[1]; S_end = seeds[0] + seeds[1] - 1; S_endBest = seeds[5]; S_maxFixed = seeds[2];
                 S_isRepeat = (seeds[3] & 1) != 0;
                 it = 1;
+            } else if(R.state == kReadYield) {
+                S_seedLen = R.s_seed_len; S_end = R.s_end; S_endBest = R.s_end_best; S_maxFixed = R.s_max_fixed; S_isRepeat = R.s_is_repeat != 0;
+                it = R.it;
             } else {
                 S_seedLen = R.s_seed_len; S_end = R.s_end; S_endBest = R.s_end_best; S_maxFixed = R.s_max_fixed; S_isRepeat = R.s_is_repeat != 0;
                 it = R.it;
@@ -142,7 +145,10 @@ __global__ __launch_bounds__(64, OCC) void correct_reads_kernel(FmIndexDev fm, C
             const int min_SA = a.pb_coverage > 60 ? (int)((a.pb_coverage / 60) * 3) : 3;
 
             const uint64_t t_all0 = __builtin_readcyclecounter();
+            uint32_t walks_here = 0;
             while(it < n_seeds && !error) {
+                if(next == 0 && a.max_walks != 0 && walks_here >= a.max_walks) { state = kReadYield; break; }
+                ++walks_here;
                 const uint64_t t0 = __builtin_readcyclecounter();
                 const int32_t* T = seeds + (uint64_t)(it + (uint32_t)next) * kSeedInts;
                 const int T_start = T[0], T_len = T[1];

@@ -52,6 +52,7 @@ struct DpMsaOut {
     uint32_t cons_len;
     uint32_t error;               // 1 = column capacity exceeded
     uint32_t pad;
+    uint32_t kc_total, kc_stage, kc_insert, n_insert;   // profiling: kilo-ticks in the whole request / staging / gap insertion; insertions
 };
 
 struct DpPipeArgs {
@@ -95,7 +96,7 @@ hipError_t launch_dp_seeds(const FmIndexDev& fm, const DpPipeArgs& a, hipStream_
 hipError_t launch_dp_retrieve(const FmIndexDev& fm, const DpPipeArgs& a, hipStream_t stream);
 // wavefront per request: MultipleAlignment::addOverlap for every accepted overlap + calculateBaseConsensus
 hipError_t launch_dp_msa(const DpPipeArgs& a, hipStream_t stream);
-uint32_t dp_msa_lds_bytes(uint32_t w_cols, uint32_t str_cap, uint32_t ops_cap, uint32_t coverage);
+uint32_t dp_msa_lds_bytes(uint32_t w_cols, uint32_t str_cap, uint32_t ops_cap, uint32_t n_str);
 // initial column capacity of one multiple alignment: the query plus the gap columns insertions may open
 constexpr uint32_t dp_msa_columns(uint32_t lq) { return 3 * lq + 128; }
 constexpr uint32_t dp_cons_capacity(uint32_t lq) { return 2 * lq + 128; }

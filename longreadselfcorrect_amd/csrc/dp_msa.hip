@@ -20,7 +20,10 @@ namespace lrsc {
 
 namespace {
 constexpr uint32_t kGap = 4;
-struct Cnt { uint16_t c[6]; };             // A C G T '-' (pad)
+// per-column counters of A C G T '-' : five 12-bit fields of one 64-bit word (at most 4095 rows)
+using Cnt = unsigned long long;
+constexpr uint32_t kCntBits = 12;
+__device__ __forceinline__ uint32_t cnt_get(Cnt v, uint32_t sym) { return (uint32_t)(v >> (kCntBits * sym)) & ((1u << kCntBits) - 1u); }
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint32_t mbcnt(uint64_t mask)
@@ -29,14 +32,13 @@ __device__ __forceinline__ uint32_t mbcnt(uint64_t mask)
 }
 } // namespace
 
-uint32_t dp_msa_lds_bytes(uint32_t w_cols, uint32_t str_cap, uint32_t ops_cap, uint32_t coverage)
+uint32_t dp_msa_lds_bytes(uint32_t w_cols, uint32_t str_cap, uint32_t ops_cap, uint32_t n_str)
 {
-    const uint32_t W = w_cols, E = 4 * coverage + 4;
+    const uint32_t W = w_cols, E = n_str + 2;
     uint32_t o = 0;
     o += W * (uint32_t)sizeof(Cnt);        // cnt
     o += E * 8;                            // lead, size
     o += (W + 3) & ~3u;                    // T
-    o += (W + 3) & ~3u;                    // outsym
     o += (str_cap + 3) & ~3u;              // S
     o += (ops_cap + 3) & ~3u;              // ops
     return o;
@@ -54,19 +56,21 @@ __global__ __launch_bounds__(64) void dp_msa_kernel(DpPipeArgs a)
     for(uint32_t wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
         const uint32_t rq = a.req_list ? a.req_list[wi] : wi;
         const DpRequest R = a.reqs[rq];
-        const uint32_t W = R.w_cols, E = 4 * R.coverage + 4;
+        const uint64_t t_req0 = __builtin_readcyclecounter();
+        uint64_t t_stage = 0, t_ins = 0;
+        uint32_t n_ins = 0;
+        const uint32_t W = R.w_cols, E = R.n_str + 2;
         Cnt* cnt = reinterpret_cast<Cnt*>(smem);
         uint32_t* lead = reinterpret_cast<uint32_t*>(smem + W * sizeof(Cnt));
         uint32_t* size = lead + E;
         uint8_t* T = reinterpret_cast<uint8_t*>(size + E);
-        uint8_t* outsym = T + ((W + 3) & ~3u);
-        uint8_t* S = outsym + ((W + 3) & ~3u);
+        uint8_t* S = T + ((W + 3) & ~3u);
         uint8_t* ops = S + ((R.str_cap + 3) & ~3u);
         __syncthreads();
         const uint8_t* q = a.codes + R.q_off;
         for(uint32_t c = lane; c < W; c += 64) {
-            Cnt z; z.c[0] = z.c[1] = z.c[2] = z.c[3] = z.c[4] = z.c[5] = 0;
-            if(c < R.lq) { T[c] = q[c]; z.c[q[c]] = 1; }
+            Cnt z = 0;
+            if(c < R.lq) { T[c] = q[c]; z = 1ull << (kCntBits * q[c]); }
             cnt[c] = z;
         }
         __syncthreads();
@@ -78,10 +82,12 @@ __global__ __launch_bounds__(64) void dp_msa_kernel(DpPipeArgs a)
             if(!A.accept) continue;
             const DpJob J = a.jobs[R.job_first + s];
             ++n_rows;
+            const uint64_t t_s0 = __builtin_readcyclecounter();
             __syncthreads();
             for(uint32_t i = lane; i < J.s2_len; i += 64) S[i] = a.strings[J.s2_off + i];
             for(uint32_t i = lane; i < A.n_ops; i += 64) ops[i] = a.ops[J.ops_off + A.n_ops - 1 - i];      // forward order
             __syncthreads();
+            t_stage += __builtin_readcyclecounter() - t_s0;
 
             // getPaddedPositionOfBase(match[0].start): index in T of the match0_start-th non-gap symbol
             uint32_t ti = 0;
@@ -103,18 +109,43 @@ __global__ __launch_bounds__(64) void dp_msa_kernel(DpPipeArgs a)
             }
             const uint32_t tl = lead_b;                         // template_leading, read once (:306)
             const uint32_t il = ti + tl;                        // incoming_leading
+            // The cigar walk is one dependent step per column.  To keep a step at register speed the next 64 bytes of the
+            // base row, of the cigar and of the incoming string sit one per lane in a register and are picked with
+            // v_readlane; the output symbols are collected the same way and counted into their columns 64 at a time.
             uint32_t inc = (uint32_t)A.m1s, cig = 0, nout = 0;
+            uint32_t tb = 0xFFFFFF00u, ob = 0xFFFFFF00u, sb = 0xFFFFFF00u, Tw = 0, Ow = 0, Sw = 0, acc = 0;
+            auto getT = [&](uint32_t i) -> uint32_t {
+                if(i - tb >= 64u) { tb = i; const uint32_t j = i + lane; Tw = j < size_b ? (uint32_t)T[j] : 0xFFu; }   // past the end: the string's NUL, not a gap
+                return (uint32_t)__builtin_amdgcn_readlane((int)Tw, (int)(i - tb));
+            };
+            auto getO = [&](uint32_t i) -> uint32_t {
+                if(i - ob >= 64u) { ob = i; const uint32_t j = i + lane; Ow = j < A.n_ops ? (uint32_t)ops[j] : 0u; }
+                return (uint32_t)__builtin_amdgcn_readlane((int)Ow, (int)(i - ob));
+            };
+            auto getS = [&](uint32_t i) -> uint32_t {
+                if(i - sb >= 64u) { sb = i; const uint32_t j = i + lane; Sw = j < J.s2_len ? (uint32_t)S[j] : 0u; }
+                return (uint32_t)__builtin_amdgcn_readlane((int)Sw, (int)(i - sb));
+            };
+            auto flush = [&](uint32_t first, uint32_t n) {                  // outputs first .. first + n land in columns il + first ..
+                const uint32_t col = il + first + lane;
+                if(lane < n && col < W) cnt[col] += 1ull << (kCntBits * acc);
+            };
             while(cig < A.n_ops) {
-                const uint32_t tsym = ti < size_b ? T[ti] : 0xFFu;          // past the end: the string's NUL, not a gap
-                const uint32_t op = ops[cig];
+                ti = (uint32_t)__builtin_amdgcn_readfirstlane((int)ti);
+                cig = (uint32_t)__builtin_amdgcn_readfirstlane((int)cig);
+                inc = (uint32_t)__builtin_amdgcn_readfirstlane((int)inc);
+                const uint32_t tsym = getT(ti);
+                const uint32_t op = getO(cig);
                 uint32_t sym;
                 if(tsym == kGap) {
-                    if(op == 'I') { sym = S[inc++]; ++cig; }
+                    if(op == 'I') { sym = getS(inc); ++inc; ++cig; }
                     else sym = kGap;
-                } else if(op == 'M') { sym = S[inc++]; ++cig; }
+                } else if(op == 'M') { sym = getS(inc); ++inc; ++cig; }
                 else if(op == 'D') { sym = kGap; ++cig; }
                 else {
                     // insertGapBeforeColumn(template_index + template_leading) on every row (:1205-1211, :165-180)
+                    const uint64_t t_i0 = __builtin_readcyclecounter();
+                    ++n_ins;
                     const uint32_t c = ti + tl;
                     uint32_t ngap = 0;
                     for(uint32_t e0 = 0; e0 < n_el; e0 += 64) {
@@ -146,13 +177,14 @@ __global__ __launch_bounds__(64) void dp_msa_kernel(DpPipeArgs a)
                         }
                         if(lane == 0) T[ip] = (uint8_t)kGap;
                         size_b += 1;
+                        tb = 0xFFFFFF00u;                                    // the register window of T is stale
                     }
                     if(c < end_b) {                                          // columns at / after c move right
                         if(end_b + 1 > W) { overflow = true; break; }
                         for(uint32_t hi = end_b; hi > c;) {
                             const uint32_t n = hi - c < 64 ? hi - c : 64;
                             const uint32_t i = hi - 1 - lane;
-                            Cnt v;
+                            Cnt v = 0;
                             if(lane < n) v = cnt[i];
                             __syncthreads();
                             if(lane < n) cnt[i + 1] = v;
@@ -160,28 +192,23 @@ __global__ __launch_bounds__(64) void dp_msa_kernel(DpPipeArgs a)
                             hi -= n;
                         }
                     }
-                    if(c < W && lane == 0) {
-                        Cnt z; z.c[0] = z.c[1] = z.c[2] = z.c[3] = z.c[5] = 0;
-                        z.c[4] = (uint16_t)(ngap + (base_inside ? 1u : 0u));
-                        cnt[c] = z;
-                    }
+                    if(c < W && lane == 0) cnt[c] = (Cnt)(ngap + (base_inside ? 1u : 0u)) << (kCntBits * kGap);
                     __syncthreads();
-                    sym = S[inc++]; ++cig;
+                    t_ins += __builtin_readcyclecounter() - t_i0;
+                    sym = getS(inc); ++inc; ++cig;
                 }
                 if(nout >= W) { overflow = true; break; }
-                if(lane == 0) outsym[nout] = (uint8_t)sym;
+                acc = lane == (nout & 63u) ? sym : acc;
                 ++nout;
+                if((nout & 63u) == 0) flush(nout - 64, 64);
                 ++ti;
             }
             if(overflow) break;
+            if((nout & 63u) != 0) flush(nout & ~63u, nout & 63u);
             __syncthreads();
             if(n_el >= E) { overflow = true; break; }
             if(lane == 0) { lead[n_el] = il; size[n_el] = nout; }
             ++n_el;
-            for(uint32_t t = lane; t < nout; t += 64) {
-                const uint32_t col = il + t;
-                if(col < W) cnt[col].c[outsym[t]] += 1;
-            }
             __syncthreads();
         }
 
@@ -197,9 +224,9 @@ __global__ __launch_bounds__(64) void dp_msa_kernel(DpPipeArgs a)
                     int max_count = -1; uint32_t max_symbol = 0;
 #pragma unroll
                     for(uint32_t x = 0; x < 5; ++x)                         // "ACGT" then '-' ('N' never counted)
-                        if((int)v.c[x] > max_count) { max_count = (int)v.c[x]; max_symbol = x; }
+                        if((int)cnt_get(v, x) > max_count) { max_count = (int)cnt_get(v, x); max_symbol = x; }
                     const uint32_t base_symbol = T[i];
-                    const int base_count = (int)v.c[base_symbol];
+                    const int base_count = (int)cnt_get(v, base_symbol);
                     sym = (max_count >= base_count && base_count < R.min_call_coverage) ? max_symbol : base_symbol;
                 }
                 const bool keep = i < size_b && sym != kGap;
@@ -215,6 +242,8 @@ __global__ __launch_bounds__(64) void dp_msa_kernel(DpPipeArgs a)
         if(lane == 0) {
             DpMsaOut o;
             o.n_rows = n_rows; o.cons_len = overflow ? 0 : cons_len; o.error = !overflow ? 0u : cons_len == 0xFFFFFFFFu ? 2u : 1u; o.pad = 0;
+            o.kc_total = (uint32_t)((__builtin_readcyclecounter() - t_req0) >> 10); o.kc_stage = (uint32_t)(t_stage >> 10);
+            o.kc_insert = (uint32_t)(t_ins >> 10); o.n_insert = n_ins;
             a.msa[rq] = o;
         }
     }
@@ -226,7 +255,7 @@ uint32_t dp_msa_waves(const DpPipeArgs& a, bool global)
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     uint32_t per_cu = global ? 8u : (a.lds_bytes ? (160u * 1024u) / a.lds_bytes : 16u);
-    per_cu = per_cu < 1 ? 1 : per_cu > 16 ? 16 : per_cu;
+    per_cu = per_cu < 1 ? 1 : per_cu > 32 ? 32 : per_cu;
     uint32_t n_waves = (uint32_t)cus * per_cu;
     const uint32_t n_work = a.req_list ? a.n_list : a.n_reqs;
     return n_waves > n_work ? n_work : n_waves;
