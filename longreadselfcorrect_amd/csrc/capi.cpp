@@ -1189,6 +1189,15 @@ struct DpStage {
                 st = timed_launch(ctx, LRSC_K_DP, [&]() { return launch_dp_align(al, nw, ctx->stream); });
                 if(st != LRSC_OK) return st;
             }
+            if(std::getenv("LRSC_CORRECT_PROFILE") && begin == 0 && jobs) {
+                std::vector<DpAlignOut> ao(jobs);
+                (void)hipMemcpy(ao.data(), d_align.p, jobs * sizeof(DpAlignOut), hipMemcpyDeviceToHost);
+                double tf = 0, tt = 0, cols = 0, na = 0;
+                for(const DpAlignOut& o : ao) if(!o.skipped) { tf += o.t_fill; tt += o.t_trace; cols += o.total_columns; na += 1; }
+                std::fprintf(stderr, "[lrsc] align: %llu jobs (%.0f aligned), %.0f columns avg, per job %.0f ticks fill + %.0f ticks traceback; lds %u B, %u waves\n",
+                             (unsigned long long)jobs, na, cols / std::max(na, 1.0), tf / std::max(na, 1.0), tt / std::max(na, 1.0),
+                             ((max1 + 2 + 3) & ~3u) + max2 + 8, (unsigned)std::min<uint64_t>((uint64_t)n_waves * 4, jobs));
+            }
             if(std::getenv("LRSC_DP_DEBUG")) {
                 std::vector<DpAlignOut> ao(jobs);
                 std::vector<DpJob> jj(jobs);

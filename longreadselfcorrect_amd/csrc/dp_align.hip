@@ -23,16 +23,24 @@ constexpr int kIntMin = -2147483647 - 1;
 
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
-// inclusive prefix max over the wave (lane order)
-__device__ __forceinline__ int wave_prefix_max(int x, uint32_t lane)
+// DPP moves (GFX9 encodings): row_shr:n = 0x110 + n, row_bcast:15 = 0x142, row_bcast:31 = 0x143, wave_shl:1 = 0x130,
+// wave_shr:1 = 0x138.  Lanes without a source (and rows masked out) receive `old`.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ int dpp(int old, int x) { return __builtin_amdgcn_update_dpp(old, x, CTRL, ROW_MASK, 0xF, false); }
+
+// inclusive prefix max over the wave (lane order): Kogge-Stone inside each row of 16, then two row broadcasts
+__device__ __forceinline__ int wave_prefix_max(int x)
 {
-#pragma unroll
-    for(int d = 1; d < 64; d <<= 1) {
-        const int t = __shfl_up(x, d);
-        if((int)lane >= d) x = imax(x, t);
-    }
+    x = imax(x, dpp<0x111>(kNeg, x));
+    x = imax(x, dpp<0x112>(kNeg, x));
+    x = imax(x, dpp<0x114>(kNeg, x));
+    x = imax(x, dpp<0x118>(kNeg, x));
+    x = imax(x, dpp<0x142, 0xA>(kNeg, x));
+    x = imax(x, dpp<0x143, 0xC>(kNeg, x));
     return x;
 }
+__device__ __forceinline__ int lane_below(int old, int x) { return dpp<0x138>(old, x); }     // value of lane - 1
+__device__ __forceinline__ int lane_above(int old, int x) { return dpp<0x130>(old, x); }     // value of lane + 1
 } // namespace
 
 __global__ __launch_bounds__(64) void dp_align_kernel(DpAlignArgs a)
@@ -51,7 +59,8 @@ __global__ __launch_bounds__(64) void dp_align_kernel(DpAlignArgs a)
         const DpJob J = a.jobs[job];
         DpAlignOut o;
         o.m0s = 0; o.m0e = -1; o.m1s = 0; o.m1e = -1; o.score = -1; o.edit_distance = -1; o.total_columns = -1; o.n_ops = 0;
-        o.accept = 0; o.skipped = 1;
+        o.accept = 0; o.skipped = 1; o.t_fill = 0; o.t_trace = 0;
+        const uint64_t t_job0 = __builtin_readcyclecounter();
         if(J.s1_len == 0 || J.s2_len == 0) {
             if(lane == 0) a.out[job] = o;
             continue;
@@ -84,7 +93,7 @@ __global__ __launch_bounds__(64) void dp_align_kernel(DpAlignArgs a)
             const bool skipcol = j_hi <= 0 || j_lo >= num_rows || j_lo >= j_hi;
             int cur[4] = {0, 0, 0, 0};
             uint32_t flags = 0;
-            const int prev_next = __shfl_down(prev[0], 1);
+            const int prev_next = lane_above(0, prev[0]);
             if(!skipcol) {
                 const uint32_t c1 = S1[i - 1];
                 const bool h1 = c1 == S1[i];
@@ -110,13 +119,12 @@ __global__ __launch_bounds__(64) void dp_align_kernel(DpAlignArgs a)
                     B[t] = inr[t] ? A - g * r : kNeg;
                 }
                 const int p0 = B[0], p1 = imax(p0, B[1]), p2 = imax(p1, B[2]), p3 = imax(p2, B[3]);
-                const int incl = wave_prefix_max(p3, lane);
-                int excl = __shfl_up(incl, 1);
-                if(lane == 0) excl = kNeg;
+                const int incl = wave_prefix_max(p3);
+                const int excl = lane_below(kNeg, incl);
                 const int P[4] = {imax(p0, excl), imax(p1, excl), imax(p2, excl), imax(p3, excl)};
 #pragma unroll
                 for(int t = 0; t < 4; ++t) cur[t] = inr[t] ? P[t] + g * (r0 + t) : 0;
-                const int below = __shfl_up(cur[3], 1);             // band row r0 - 1 of this column
+                const int below = lane_below(0, cur[3]);            // band row r0 - 1 of this column
 #pragma unroll
                 for(int t = 0; t < 4; ++t) {
                     if(!inr[t]) continue;
@@ -173,6 +181,7 @@ __global__ __launch_bounds__(64) void dp_align_kernel(DpAlignArgs a)
         o.edit_distance = 0; o.total_columns = 0;
 
         // ---- traceback ----------------------------------------------------------------------------------------
+        const uint64_t t_job1 = __builtin_readcyclecounter();
         __threadfence();
         uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
         int wb = -1;                                                // first column of the 16-column window held in w0..w3
@@ -206,6 +215,7 @@ __global__ __launch_bounds__(64) void dp_align_kernel(DpAlignArgs a)
         if((n_ops & 63u) != 0 && lane < (n_ops & 63u)) ops[(n_ops & ~63u) + lane] = (uint8_t)acc;
         o.m0s = ti; o.m1s = tj;
         o.n_ops = bad ? 0xFFFFFFFFu : n_ops;
+        o.t_fill = (uint32_t)(t_job1 - t_job0); o.t_trace = (uint32_t)(__builtin_readcyclecounter() - t_job1);
         if(a.reqs && !bad) {
             const DpRequest& R = a.reqs[J.req];
             const bool bPassedOverlap = (uint64_t)(int64_t)o.total_columns >= (uint64_t)R.min_overlap;

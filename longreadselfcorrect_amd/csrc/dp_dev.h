@@ -30,6 +30,7 @@ struct DpAlignOut {               // SequenceOverlap (Thirdparty/overlapper.h:69
     uint32_t n_ops;               // expanded cigar, stored LAST op first: op t of the cigar is ops[n_ops - 1 - t]
     uint32_t accept;              // aligned, overlap length >= min_overlap and identity >= min_identity (LongReadOverlap.cpp:645-655)
     uint32_t skipped;
+    uint32_t t_fill, t_trace;     // profiling: ticks spent in the DP fill / the traceback
 };
 
 // one correctByMSAlignment call (PacBioSelfCorrectionProcess.cpp:208-245)
