@@ -194,7 +194,9 @@ static int index_from_units_impl(const uint8_t* u0, uint64_t n0, const uint8_t* 
     if(!idx) return fail(LRSC_ERR_NOMEM, "lrsc_index");
     idx->num_strings = num_strings;
     idx->num_symbols = num_symbols;
-    idx->wide = num_symbols >= (1ull << 31);
+    // Block64 (64-bit counters, 128 symbols per block) from 2^31 symbols per strand; LRSC_FORCE_WIDE=1 selects it for any
+    // index so that the wide code path can be tested on small data
+    idx->wide = num_symbols >= (1ull << 31) || std::getenv("LRSC_FORCE_WIDE") != nullptr;
     int st[2] = {LRSC_OK, LRSC_OK};
     std::string err[2];
     const uint8_t* us[2] = {u0, u1};
@@ -1416,8 +1418,12 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
 
     // With the DP fallback on, a read runs at most max_walks walks per launch: a round then lasts about as long as
     // max_walks walks instead of as long as the luckiest read's failure-free stretch, and parked reads get their answer sooner.
-    a.max_walks = p.no_dp ? 0u : 8u;
+    a.setup_quorum_pct = 40;
+    if(const char* e = std::getenv("LRSC_CORRECT_QUORUM")) a.setup_quorum_pct = (uint32_t)std::min(100, std::max(0, std::atoi(e)));
+    a.max_walks = p.no_dp ? 0u : 64u;
+    a.max_steps = 2000;
     if(const char* e = std::getenv("LRSC_CORRECT_MAX_WALKS")) a.max_walks = (uint32_t)std::max(0, std::atoi(e));
+    if(const char* e = std::getenv("LRSC_CORRECT_MAX_STEPS")) a.max_steps = (uint32_t)std::max(1, std::atoi(e));
     int st = timed_launch(ctx, LRSC_K_EXTEND, [&]() { return launch_correct_reads(ctx->fm, a, ctx->stream); });
     if(st != LRSC_OK) return st;
 

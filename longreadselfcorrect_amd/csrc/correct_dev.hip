@@ -145,22 +145,38 @@ __global__ __launch_bounds__(64, OCC) void correct_reads_kernel(FmIndexDev fm, C
             const int min_SA = a.pb_coverage > 60 ? (int)((a.pb_coverage / 60) * 3) : 3;
 
             const uint64_t t_all0 = __builtin_readcyclecounter();
+            // The lanes of a wavefront stay together in Walk::step(): a lane whose walk has ended handles the result and sets
+            // up its next walk (the `!in_walk` branch) while the others wait for it, instead of every lane idling until the
+            // longest walk of the wavefront is over.
             uint32_t walks_here = 0;
-            while(it < n_seeds && !error) {
-                if(next == 0 && a.max_walks != 0 && walks_here >= a.max_walks) { state = kReadYield; break; }
+            const uint64_t steps0 = W.steps;
+            bool in_walk = false;
+            const int32_t* T = seeds;
+            int T_start = 0, T_len = 0, interval = 0, k = 0, trg_len = 0;
+            bool T_isRepeat = false, rtou = false;
+            while(true) {
+              // setting up a walk stalls every stepping lane of the wavefront, so lanes between walks wait until a quorum of
+              // the wavefront's live lanes is between walks (lanes that are done leave the loop and stop counting)
+              const uint32_t n_all = (uint32_t)__builtin_popcountll(__ballot(true));
+              const uint32_t n_need = (uint32_t)__builtin_popcountll(__ballot(!in_walk));
+              const bool setup_now = n_need * 100u >= n_all * a.setup_quorum_pct;
+              if(!in_walk) {
+                if(!(it < n_seeds) || error) break;
+                if(next == 0 && a.max_walks != 0 && (walks_here >= a.max_walks || W.steps - steps0 >= (uint64_t)a.max_steps)) { state = kReadYield; break; }
+                if(!setup_now) continue;
                 ++walks_here;
                 const uint64_t t0 = __builtin_readcyclecounter();
-                const int32_t* T = seeds + (uint64_t)(it + (uint32_t)next) * kSeedInts;
-                const int T_start = T[0], T_len = T[1];
-                const bool T_isRepeat = (T[3] & 1) != 0;
-                const int interval = T_start - S_end - 1;
-                int k = (S_endBest < T[4] ? S_endBest : T[4]) - 2;                 // min(source.endBest, target.startBest) - 2
+                T = seeds + (uint64_t)(it + (uint32_t)next) * kSeedInts;
+                T_start = T[0]; T_len = T[1];
+                T_isRepeat = (T[3] & 1) != 0;
+                interval = T_start - S_end - 1;
+                k = (S_endBest < T[4] ? S_endBest : T[4]) - 2;                     // min(source.endBest, target.startBest) - 2
                 if(S_isRepeat || T_isRepeat) {
                     k = S_seedLen < T_len ? S_seedLen : T_len;
                     k = k < a.start_kmer_len + 2 ? k : a.start_kmer_len + 2;
                 }
-                const bool rtou = S_isRepeat && !T_isRepeat;
-                const int trg_len = rtou ? k : T_len;
+                rtou = S_isRepeat && !T_isRepeat;
+                trg_len = rtou ? k : T_len;
                 if(k < (int)a.seed_size || k > (int)kMaxInitK || k > S_seedLen || interval < 0 || trg_len < (int)a.min_overlap ||
                    (uint32_t)(k + interval + trg_len) > rw.lq_max) { error = LRSC_WALK_ERR_GEOMETRY; break; }
                 const uint32_t Lq = (uint32_t)(k + interval + trg_len);
@@ -187,10 +203,14 @@ __global__ __launch_bounds__(64, OCC) void correct_reads_kernel(FmIndexDev fm, C
                 W.maxLength = (uint64_t)((1.2 * (interval + 10)) + (double)(2 * (uint64_t)k));
                 W.minLength = (uint64_t)((0.8 * (interval - 20)) + (double)(2 * (uint64_t)k));
                 W.n_term = (uint32_t)trg_len - a.min_overlap + 1;
+                cyc_prep += __builtin_readcyclecounter() - t0;
+                W.begin();
+                in_walk = true;
+              }
+                if(W.step()) continue;
+                in_walk = false;
                 uint32_t plen = 0, mi = 0;
-                const uint64_t t1 = __builtin_readcyclecounter();
-                cyc_prep += t1 - t0;
-                const int code = W.run(&plen, best, &mi);
+                const int code = W.finish(&plen, best, &mi);
                 if(code <= LRSC_WALK_ERR_CHILDREN) { error = code; break; }
                 if(next == 0) firstType = code;
 

@@ -495,8 +495,19 @@ struct Walk {
         r.path_len = len;
     }
 
-    // ---- one walk ----------------------------------------------------------------------------------------------
+    // ---- one walk = begin() + step() until it returns false + finish() ------------------------------------------
+    // (split so that the persistent kernel can keep all lanes of a wavefront in the step loop: a lane whose walk
+    //  ended sets up its next one while the others wait, instead of idling until the longest walk of the wave ends)
     __device__ int run(uint32_t* out_len, uint32_t* out_words, uint32_t* out_match_i)
+    {
+        begin();
+        while(step()) {}
+        return finish(out_len, out_words, out_match_i);
+    }
+
+    bool ended;                        // the frontier overflowed maxLeaves: the loop ends after this isTerminated
+
+    __device__ __noinline__ void begin()
     {
         const uint64_t t_run0 = __builtin_readcyclecounter();
         // --- interval "trees": compact the valid 9-mer entries (emplace_back order), introsort, chain by k-mer ---
@@ -555,13 +566,25 @@ struct Walk {
         rings[0] = 0.0;
         for(uint32_t t = 0; t < initk; ++t) path_set(paths, t, q[t]);
         n_cur = 1; n_nxt = 0; n_results = 0;
+        ended = false;
+        cyc_setup += __builtin_readcyclecounter() - t_run0;
+    }
 
-        const uint64_t t_run1 = __builtin_readcyclecounter();
-        cyc_setup += t_run1 - t_run0;
-        // --- extendOverlap (.cpp:155-211) ---
-        while(n_cur != 0 && n_cur <= maxLeaves && currentLength <= maxLength) {
+    // one iteration of extendOverlap's loop (.cpp:155-211); false when the loop is over (or on an internal error)
+    __device__ bool step()
+    {
+        if(ended || error || !(n_cur != 0 && n_cur <= maxLeaves && currentLength <= maxLength)) return false;
+        const uint64_t t_step0 = __builtin_readcyclecounter();
+        step_body();
+        cyc_loop += __builtin_readcyclecounter() - t_step0;
+        return true;
+    }
+
+    __device__ void step_body()
+    {
+        {
             extendLeaves();
-            if(error) return error;
+            if(error) return;
             PrunedBySeedSupport();
             uint32_t survivors = 0;
             for(uint32_t c = 0; c < n_nxt; ++c) survivors += nxt[c].alive;
@@ -573,10 +596,11 @@ struct Walk {
                         if(!nxt[c].alive) continue;
                         const Leaf<P>& par = cur[nxt[c].parent];
                         terminated_leaf(nxt[c], paths + (uint64_t)par.path * pathw, par.path_len, (int)nxt[c].ext);
-                        if(error) return error;
+                        if(error) return;
                     }
                 n_cur = survivors;
-                break;
+                ended = true;
+                return;
             }
             // materialise the survivors: the first surviving child of a parent takes over its ring and path
             // in place (SAINode::extend), further ones get copies (createChild)
@@ -621,11 +645,14 @@ struct Walk {
             if(currentLength >= minLength)
                 for(uint32_t i = 0; i < n_cur; ++i) {
                     terminated_leaf(cur[i], paths + (uint64_t)cur[i].path * pathw, cur[i].path_len, -1);
-                    if(error) return error;
+                    if(error) return;
                 }
         }
+    }
 
-        cyc_loop += __builtin_readcyclecounter() - t_run1;
+    __device__ __noinline__ int finish(uint32_t* out_len, uint32_t* out_words, uint32_t* out_match_i)
+    {
+        if(error) return error;
         // --- findTheBestPath (.cpp:214-236) ---
         if(n_results > 0) {
             double minErrorRate = 1;

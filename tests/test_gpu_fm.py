@@ -540,3 +540,50 @@ def test_repeat_dataset_with_dp_fallback(api, rep_index, oracle, repeat_ds):
     p = api.params_default(5, 90)
     p.no_dp = 0
     _check_whole_path(api, rep_index, oracle, repeat_ds, p, n_reads=120, min_fm=100, min_dp=5)
+
+
+# ---- the wide layout (Block64: 64-bit counters, 128 symbols per block; indexes of >= 2^31 symbols per strand) --------
+@pytest.fixture(scope="module")
+def wide_index(api, small_ds):
+    import os
+    os.environ["LRSC_FORCE_WIDE"] = "1"
+    try:
+        idx = api.index_open(small_ds.prefix + ".bwt", small_ds.prefix + ".rbwt")
+    finally:
+        del os.environ["LRSC_FORCE_WIDE"]
+    idx.upload(0)
+    assert idx.info().block_symbols == 128
+    yield idx
+    idx.close()
+
+
+def test_wide_layout_rank_chars_kmers_seeds(api, wide_index, oracle, small_ds):
+    p = api.params_default(5, 90)
+    ctx = wide_index.ctx(p, 0)
+    ob, orb = oracle.bwt_load(small_ds.prefix + ".bwt"), oracle.bwt_load(small_ds.prefix + ".rbwt")
+    rng = np.random.default_rng(5)
+    n = ob.num_symbols
+    for strand, o in ((0, ob), (1, orb)):
+        idx = np.concatenate([rng.integers(-1, n, 50000), np.array([-1, 0, 1, 127, 128, 129, 255, 256, n - 2, n - 1]),
+                              np.arange(-1, min(n, 2048))]).astype(np.int64)
+        base = rng.choice(ACGT, size=idx.size)
+        np.testing.assert_array_equal(ctx.rank(base, idx, strand), o.occ(base, idx))
+        rows = np.arange(0, n, 7, dtype=np.uint64)
+        np.testing.assert_array_equal(ctx.bwt_chars(strand, rows), o.chars(rows))
+    count, seeds, attr = None, None, None
+    b = ctx.batch(small_ds.bases, small_ds.off)
+    b.find_seeds()
+    count, seeds, attr = b.seeds()
+    b.close()
+    wcount, wseeds, wattr = oracle.find_seeds(ob, orb, p, small_ds.bases, small_ds.off)
+    np.testing.assert_array_equal(attr, wattr)
+    np.testing.assert_array_equal(count, wcount)
+    np.testing.assert_array_equal(np.stack([seeds[f] for f in seeds.dtype.names], axis=1), wseeds)
+    ctx.close(); ob.close(); orb.close()
+
+
+@pytest.mark.parametrize("nodp", [1, 0])
+def test_wide_layout_whole_path(api, wide_index, oracle, small_ds, nodp):
+    p = api.params_default(5, 90)
+    p.no_dp = nodp
+    _check_whole_path(api, wide_index, oracle, small_ds, p, min_fm=300, min_dp=0 if nodp else 20)
