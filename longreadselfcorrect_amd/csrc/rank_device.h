@@ -42,6 +42,28 @@ template <> struct Lay<false> {
         c += __builtin_popcount((r.q[3].y ^ L) & (r.q[3].w ^ H) & m1.y);
         return c;
     }
+    // the same for two prefix lengths of one block
+    static __device__ __forceinline__ void count2(const Regs& r, uint32_t code, const uint32_t* __restrict__ mrow_a,
+                                                  const uint32_t* __restrict__ mrow_b, uint64_t& ca, uint64_t& cb)
+    {
+        const uint32_t base = code == 0 ? (r.q[0].x & ~kFlag32) : code == 1 ? r.q[0].y : code == 2 ? r.q[0].z : r.q[0].w;
+        const uint32_t L = (code & 1u) ? 0u : 0xFFFFFFFFu;
+        const uint32_t H = (code & 2u) ? 0u : 0xFFFFFFFFu;
+        const uint32_t m[6] = {(r.q[1].x ^ L) & (r.q[1].z ^ H), (r.q[1].y ^ L) & (r.q[1].w ^ H), (r.q[2].x ^ L) & (r.q[2].z ^ H),
+                               (r.q[2].y ^ L) & (r.q[2].w ^ H), (r.q[3].x ^ L) & (r.q[3].z ^ H), (r.q[3].y ^ L) & (r.q[3].w ^ H)};
+        const uint4 a0 = *reinterpret_cast<const uint4*>(mrow_a);
+        const uint2 a1 = *reinterpret_cast<const uint2*>(mrow_a + 4);
+        const uint4 b0 = *reinterpret_cast<const uint4*>(mrow_b);
+        const uint2 b1 = *reinterpret_cast<const uint2*>(mrow_b + 4);
+        uint32_t x = base, y = base;
+        x += __builtin_popcount(m[0] & a0.x); y += __builtin_popcount(m[0] & b0.x);
+        x += __builtin_popcount(m[1] & a0.y); y += __builtin_popcount(m[1] & b0.y);
+        x += __builtin_popcount(m[2] & a0.z); y += __builtin_popcount(m[2] & b0.z);
+        x += __builtin_popcount(m[3] & a0.w); y += __builtin_popcount(m[3] & b0.w);
+        x += __builtin_popcount(m[4] & a1.x); y += __builtin_popcount(m[4] & b1.x);
+        x += __builtin_popcount(m[5] & a1.y); y += __builtin_popcount(m[5] & b1.y);
+        ca = x; cb = y;
+    }
     static __device__ __forceinline__ uint32_t symbol(const Regs& r, uint32_t off)
     {
         const uint32_t lo[6] = {r.q[1].x, r.q[1].y, r.q[2].x, r.q[2].y, r.q[3].x, r.q[3].y};
@@ -79,6 +101,24 @@ template <> struct Lay<true> {
         c += __builtin_popcount((r.q[2].z ^ L) & (r.q[3].z ^ H) & m0.z);
         c += __builtin_popcount((r.q[2].w ^ L) & (r.q[3].w ^ H) & m0.w);
         return base + c;
+    }
+    static __device__ __forceinline__ void count2(const Regs& r, uint32_t code, const uint32_t* __restrict__ mrow_a,
+                                                  const uint32_t* __restrict__ mrow_b, uint64_t& ca, uint64_t& cb)
+    {
+        const uint64_t base = code == 0 ? (u64(r.q[0].x, r.q[0].y) & ~kFlag64) : code == 1 ? u64(r.q[0].z, r.q[0].w)
+                            : code == 2 ? u64(r.q[1].x, r.q[1].y) : u64(r.q[1].z, r.q[1].w);
+        const uint32_t L = (code & 1u) ? 0u : 0xFFFFFFFFu;
+        const uint32_t H = (code & 2u) ? 0u : 0xFFFFFFFFu;
+        const uint32_t m[4] = {(r.q[2].x ^ L) & (r.q[3].x ^ H), (r.q[2].y ^ L) & (r.q[3].y ^ H), (r.q[2].z ^ L) & (r.q[3].z ^ H),
+                               (r.q[2].w ^ L) & (r.q[3].w ^ H)};
+        const uint4 a0 = *reinterpret_cast<const uint4*>(mrow_a);
+        const uint4 b0 = *reinterpret_cast<const uint4*>(mrow_b);
+        uint32_t x = 0, y = 0;
+        x += __builtin_popcount(m[0] & a0.x); y += __builtin_popcount(m[0] & b0.x);
+        x += __builtin_popcount(m[1] & a0.y); y += __builtin_popcount(m[1] & b0.y);
+        x += __builtin_popcount(m[2] & a0.z); y += __builtin_popcount(m[2] & b0.z);
+        x += __builtin_popcount(m[3] & a0.w); y += __builtin_popcount(m[3] & b0.w);
+        ca = base + x; cb = base + y;
     }
     static __device__ __forceinline__ uint32_t symbol(const Regs& r, uint32_t off)
     {
@@ -185,10 +225,16 @@ __device__ __forceinline__ IvT<typename Lay<WIDE>::pos_t> update_interval(const 
     const uint32_t ol = (uint32_t)(pl - bl * L::kSyms), ou = (uint32_t)(pu - bu * L::kSyms);
     typename L::Regs ra, rb;
     L::load(s.blocks, bl, ra);
-    rb = ra;
-    if(bu != bl) L::load(s.blocks, bu, rb);
-    uint64_t ca = L::count(ra, code, mtab + ol * L::kRow);
-    uint64_t cb = L::count(rb, code, mtab + ou * L::kRow);
+    uint64_t ca, cb;
+    if(bu == bl) {
+        // both rank positions in one block (the rule once an interval is small): match words once, two masked popcounts
+        L::count2(ra, code, mtab + ol * L::kRow, mtab + ou * L::kRow, ca, cb);
+        rb = ra;
+    } else {
+        L::load(s.blocks, bu, rb);
+        ca = L::count(ra, code, mtab + ol * L::kRow);
+        cb = L::count(rb, code, mtab + ou * L::kRow);
+    }
     if(code == 0) {
         if(ol != 0 && L::flagged(ra)) ca -= dollars_in_c(s, (uint64_t)bl * L::kSyms, (uint64_t)bl * L::kSyms + ol);
         if(ou != 0 && L::flagged(rb)) cb -= dollars_in_c(s, (uint64_t)bu * L::kSyms, (uint64_t)bu * L::kSyms + ou);
