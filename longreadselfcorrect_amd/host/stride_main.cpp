@@ -10,6 +10,7 @@
 #include <fstream>
 #include <iostream>
 #include <sstream>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -243,6 +244,28 @@ static int indexMain(int argc, char** argv)
         lrscOrDie(lrsc_build_bwt(bases.data(), off.data(), n, rev, device, &units, &nu), "lrsc_build_bwt");
         lrscOrDie(lrsc_write_bwt_file((prefix + (rev ? RBWT_EXT : BWT_EXT)).c_str(), units, nu, n, bases.size() + n), "lrsc_write_bwt_file");
         lrsc_buffer_free(units);
+        // .sai / .rsai: lexicographic rank -> read index (SampledSuffixArray::buildLexicoIndex + writeLexicoIndex,
+        // SuffixTools/SampledSuffixArray.cpp:158-190,248-258; text format of SAWriter.cpp:32-54).  The reference LF-walks each
+        // read back to its '$' row; that row's rank among the '$' rows is the rank of the read among all reads compared as
+        // strings ('$' < A < C < G < T, so a proper prefix sorts first) with equal reads in input order (sentinel order
+        // MR_SO_IO) -- computed directly here.  `pbcorrect` only needs the file to exist.
+        std::vector<uint32_t> order(n);
+        for(uint32_t i = 0; i < n; ++i) order[i] = i;
+        const char* B = bases.data();
+        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+            const uint64_t lx = off[x + 1] - off[x], ly = off[y + 1] - off[y];
+            const uint64_t m = lx < ly ? lx : ly;
+            for(uint64_t t = 0; t < m; ++t) {
+                const char cx = rev ? B[off[x + 1] - 1 - t] : B[off[x] + t], cy = rev ? B[off[y + 1] - 1 - t] : B[off[y] + t];
+                if(cx != cy) return cx < cy;
+            }
+            if(lx != ly) return lx < ly;
+            return x < y;
+        });
+        std::ofstream sai((prefix + (rev ? ".rsai" : ".sai")).c_str());
+        sai << 51914 << "\n" << n << "\n" << n << "\n";
+        for(uint32_t i = 0; i < n; ++i) sai << order[i] << " 0\n";
+        if(!sai) { std::cerr << "index: cannot write " << prefix << (rev ? ".rsai" : ".sai") << "\n"; return EXIT_FAILURE; }
     }
     return 0;
 }

@@ -110,6 +110,27 @@ def test_stride_index_and_pbcorrect_end_to_end(stride, api, oracle, small_ds, tm
     subprocess.run([stride, "index", "-p", str(prefix), str(fa)], check=True, capture_output=True)
     for ext in ("bwt", "rbwt"):
         assert open(f"{prefix}.{ext}", "rb").read() == open(f"{small_ds.prefix}.{ext}", "rb").read()
+    # .sai / .rsai = SampledSuffixArray::buildLexicoIndex: LF-walk every read back to its '$' row (done here with the oracle's
+    # getChar / getOcc / getPC, all reads in lock-step); the row's rank among the '$' rows is the line the read is written on
+    for ext, sai in (("bwt", "sai"), ("rbwt", "rsai")):
+        ob = oracle.bwt_load(f"{small_ds.prefix}.{ext}")
+        n = len(small_ds.reads)
+        idx = np.arange(n, dtype=np.int64)
+        rank = np.full(n, -1, dtype=np.int64)
+        live = np.ones(n, dtype=bool)
+        while live.any():
+            rows = idx[live]
+            ch = ob.chars(rows.astype(np.uint64))
+            nxt = np.array([ob.pc(chr(c)) for c in ch], dtype=np.int64) + ob.occ(ch, rows - 1).astype(np.int64)
+            done = ch == ord("$")
+            li = np.flatnonzero(live)
+            rank[li[done]] = nxt[done]
+            idx[li] = nxt
+            live[li[done]] = False
+        want = ["51914", str(n), str(n)] + [f"{r} 0" for r in np.argsort(rank)]
+        assert sorted(rank.tolist()) == list(range(n))
+        assert open(f"{prefix}.{sai}").read().split("\n")[:-1] == want
+        ob.close()
     out = tmp_path / "out"
     cmd = [stride, "pbcorrect", "-p", str(prefix), "-o", str(out), "-c", "90", "-g", "5", "--batch", "70"]
     if nodp:
