@@ -141,7 +141,7 @@ def main():
     # HBM-side traffic of the same kernel on the same workload comes from the committed rocprofv3 --pmc
     # pass (it cannot be sampled from inside the process); null for any other workload.
     traffic, traffic_src = None, None
-    pmc = REPO / "profiles" / "r01_pmc" / "traffic_v8.json"
+    pmc = REPO / "profiles" / "r01_pmc" / "traffic_v10.json"
     if pmc.exists() and n_reads == 100_000 and abs(args.genome_mb - 11.1) < 1e-9 and args.read_len == 10_000:
         pj = json.loads(pmc.read_text())
         traffic, traffic_src = pj["traffic_bytes_per_launch"] / 1e9, pj["source"]
