@@ -47,6 +47,9 @@ def main():
     ap.add_argument("--reads", type=int, default=100_000, help="reads per GPU (= index reads on rank 0)")
     ap.add_argument("--read-len", type=int, default=10_000)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 disables)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="correct stages only: split the rank's reads over this many contexts on the same GPU, run concurrently "
+                         "(one host thread each) -- the tail of one sub-batch's DP rounds overlaps the other's extension")
     ap.add_argument("--stage", choices=["seeds", "correct-nodp", "correct"], default="seeds",
                     help="seeds: BASELINE configs[1] (Occ-rank + LongReadProbe kernels, the default and the graded line); "
                          "correct-nodp / correct: configs[2], the whole per-read path on the device without / with the DP fallback")
@@ -99,24 +102,46 @@ def main():
     else:
         bases, off = api.synth_reads(0x5EED0002, genome, n_reads, args.read_len,
                                      first_read=lrdist.weak_shard_first_read(rank, n_reads))
-    batch = ctx.batch(bases, off)
+    n_streams = max(1, args.streams) if args.stage != "seeds" else 1
+    ctxs = [ctx] + [index.ctx(params, local_rank) for _ in range(n_streams - 1)]
+    cuts = [len(off) - 1] if n_streams == 1 else [((len(off) - 1) * (i + 1)) // n_streams for i in range(n_streams)]
+    batches, lo = [], 0
+    for c, hi in zip(ctxs, cuts):
+        sub_off = (off[lo: hi + 1] - off[lo]).astype(np.uint64)
+        batches.append(c.batch(bases[int(off[lo]): int(off[hi])], sub_off))
+        lo = hi
+    batch = batches[0]
     my_bases = int(off[-1])
-    log(f"batch resident in HBM: {my_bases / 1e6:.1f} Mbases")
+    log(f"batch resident in HBM: {my_bases / 1e6:.1f} Mbases in {n_streams} sub-batch(es)")
 
     fm_walks = [0, 0, 0]
 
-    def step():
-        batch.find_seeds()      # k-mer grid (Occ-rank kernel) + getSeqAttribute + greedy seed scan, all on the device
+    def run_one(b, acc):
+        b.find_seeds()          # k-mer grid (Occ-rank kernel) + getSeqAttribute + greedy seed scan, all on the device
         if args.stage != "seeds":
-            res, _, _ = batch.correct()      # chain of seed-to-seed FM-extensions (+ DP/MSA rounds) and stitching, on the device
-            fm_walks[0] = sum(r.total_walk_num for r in res); fm_walks[1] = sum(r.fm_num for r in res); fm_walks[2] = sum(r.dp_num for r in res)
+            res, _, _ = b.correct()          # chain of seed-to-seed FM-extensions (+ DP/MSA rounds) and stitching, on the device
+            acc.append((sum(r.total_walk_num for r in res), sum(r.fm_num for r in res), sum(r.dp_num for r in res)))
+
+    def step():
+        acc = []
+        if len(batches) == 1:
+            run_one(batches[0], acc)
+        else:
+            import threading
+            ts = [threading.Thread(target=run_one, args=(b, acc)) for b in batches]
+            for t in ts: t.start()
+            for t in ts: t.join()
+        for j in range(3):
+            fm_walks[j] = sum(a[j] for a in acc)
 
     for _ in range(args.warmup):
         step()
-    ctx.stats_reset()
+    for c in ctxs:
+        c.stats_reset()
 
     def fence():
-        ctx.sync()
+        for c in ctxs:
+            c.sync()
         torch.cuda.synchronize()
         lrdist.barrier()
         torch.cuda.synchronize()
@@ -170,10 +195,11 @@ def main():
                                  "getSeqAttribute + searchSeedsWithHybridKmers + estimateBestKmerSize + removeHitchhikingSeeds"],
                 "stage_ms": {"kmer_grid": kernel_ms, "seed_scan_group": st_seeds.total_ms / max(st_seeds.launches, 1),
                              **({} if args.stage == "seeds" else {
-                                 "fm_extend_and_stitch": ctx.stats(K_EXTEND).total_ms / args.steps,
-                                 "dp_retrieve_lf_walks": ctx.stats(K_LF).total_ms / args.steps,
-                                 "dp_extend_match": ctx.stats(K_DP).total_ms / args.steps,
-                                 "dp_msa_consensus": ctx.stats(K_MSA).total_ms / args.steps})},
+                                 "fm_extend_and_stitch": sum(c.stats(K_EXTEND).total_ms for c in ctxs) / args.steps,
+                                 "dp_retrieve_lf_walks": sum(c.stats(K_LF).total_ms for c in ctxs) / args.steps,
+                                 "dp_extend_match": sum(c.stats(K_DP).total_ms for c in ctxs) / args.steps,
+                                 "dp_msa_consensus": sum(c.stats(K_MSA).total_ms for c in ctxs) / args.steps,
+                                 "concurrent_contexts": n_streams})},
                 **({} if args.stage == "seeds" else {"stage": args.stage, "walks_per_step": fm_walks[0], "fm_walks": fm_walks[1], "dp_walks": fm_walks[2]}),
                 "index_hbm_gb": info.device_bytes / 1e9,
                 "reads_per_gpu": n_reads,
@@ -200,8 +226,10 @@ def main():
             result["cpu_baseline"] = cpu_baseline(units, n_reads, n_sym, params, bases, off, args.cpu_seconds, args.stage)
         print(json.dumps(result), flush=True)
 
-    batch.close()
-    ctx.close()
+    for b in batches:
+        b.close()
+    for c in ctxs:
+        c.close()
     index.close()
     if world > 1:
         dist.destroy_process_group()

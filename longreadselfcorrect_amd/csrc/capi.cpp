@@ -1117,6 +1117,18 @@ struct DpStage {
     DevBuf<DpJob> d_jobs;
     DevBuf<DpAlignOut> d_align;
     uint64_t cons_total = 0, n_strings = 0;
+    // the MSA size buckets of a round run concurrently on side streams (each bucket's launch ends with a tail of a few long
+    // pile-ups; serialised, those tails cost more than the work)
+    static constexpr int kSide = 8;
+    hipStream_t side[kSide] = {};
+    hipEvent_t side_done[kSide] = {};
+    ~DpStage()
+    {
+        for(int i = 0; i < kSide; ++i) {
+            if(side_done[i]) (void)hipEventDestroy(side_done[i]);
+            if(side[i]) (void)hipStreamDestroy(side[i]);
+        }
+    }
 
     int run(lrsc_ctx* ctx, const uint8_t* d_query_codes, std::vector<DpRequest>& reqs)
     {
@@ -1230,28 +1242,60 @@ struct DpStage {
             while(!todo.empty()) {
                 static const uint32_t kBuckets[] = {8u << 10, 12u << 10, 16u << 10, 24u << 10, 40u << 10, 80u << 10, 160u << 10, 0xFFFFFFFFu};
                 const bool force_global = std::getenv("LRSC_MSA_FORCE_GLOBAL") != nullptr;     // test hook for the global-workspace variant
+                // one launch per bucket, all in flight together
+                struct Launch { DpPipeArgs args; };
+                std::vector<Launch> launches;
+                std::vector<uint32_t> all_lists;
                 uint32_t lo = 0;
+                uint64_t ws_bytes = 0;
                 for(uint32_t bk : kBuckets) {
                     if(force_global && bk != 0xFFFFFFFFu) continue;
-                    list.clear();
+                    const size_t first = all_lists.size();
                     uint32_t need_max = 0;
                     for(uint32_t i : todo) {
                         const DpRequest& r = reqs[begin + i];
                         const uint32_t need = dp_msa_lds_bytes(r.w_cols, r.str_cap, r.ops_cap, r.n_str);
-                        if(need > lo && need <= bk) { list.push_back(i); need_max = std::max(need_max, need); }
+                        if(need > lo && need <= bk) { all_lists.push_back(i); need_max = std::max(need_max, need); }
                     }
                     lo = bk;
-                    if(list.empty()) continue;
-                    HIP_TRY(hipMemcpyAsync(d_list.p, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-                    DpPipeArgs c2 = c;
-                    c2.req_list = d_list.p; c2.n_list = (uint32_t)list.size(); c2.lds_bytes = (need_max + 15) & ~15u;
+                    if(all_lists.size() == first) continue;
+                    Launch L;
+                    L.args = c;
+                    L.args.req_list = reinterpret_cast<const uint32_t*>(first);          // offset for now, pointer after the upload
+                    L.args.n_list = (uint32_t)(all_lists.size() - first);
+                    L.args.lds_bytes = (need_max + 15) & ~15u;
                     if(bk == 0xFFFFFFFFu) {
-                        HIP_TRY(d_msa_ws.reserve((uint64_t)c2.lds_bytes * dp_msa_waves(c2, true)));
-                        c2.msa_ws = d_msa_ws.p;
+                        ws_bytes = (uint64_t)L.args.lds_bytes * dp_msa_waves(L.args, true);
+                        L.args.msa_ws = reinterpret_cast<uint8_t*>(1);                     // marker, set below
                     }
-                    st = timed_launch(ctx, LRSC_K_MSA, [&]() { return launch_dp_msa(c2, ctx->stream); });
-                    if(st != LRSC_OK) return st;
+                    launches.push_back(L);
                 }
+                HIP_TRY(d_list.reserve(std::max<size_t>(all_lists.size(), 1)));
+                if(ws_bytes) HIP_TRY(d_msa_ws.reserve(ws_bytes));
+                HIP_TRY(hipMemcpyAsync(d_list.p, all_lists.data(), all_lists.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+                for(Launch& L : launches) {
+                    L.args.req_list = d_list.p + reinterpret_cast<size_t>(L.args.req_list);
+                    if(L.args.msa_ws) L.args.msa_ws = d_msa_ws.p;
+                }
+                for(int i = 0; i < kSide; ++i) {
+                    if(!side[i]) HIP_TRY(hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking));
+                    if(!side_done[i]) HIP_TRY(hipEventCreateWithFlags(&side_done[i], hipEventDisableTiming));
+                }
+                st = timed_launch(ctx, LRSC_K_MSA, [&]() -> hipError_t {
+                    // ctx->ev0 was just recorded on ctx->stream: the side streams start after it (and after the list upload)
+                    hipError_t e = hipSuccess;
+                    for(size_t j = 0; j < launches.size() && e == hipSuccess; ++j) {
+                        hipStream_t sj = side[j % kSide];
+                        e = hipStreamWaitEvent(sj, ctx->ev0, 0);
+                        if(e == hipSuccess) e = launch_dp_msa(launches[j].args, sj);
+                    }
+                    for(int i = 0; i < kSide && e == hipSuccess; ++i) {
+                        e = hipEventRecord(side_done[i], side[i]);
+                        if(e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, side_done[i], 0);
+                    }
+                    return e;
+                });
+                if(st != LRSC_OK) return st;
                 HIP_TRY(hipMemcpy(mo.data(), d_msa.p + begin, (size_t)nc * sizeof(DpMsaOut), hipMemcpyDeviceToHost));
                 list.clear();
                 for(uint32_t i : todo) {
