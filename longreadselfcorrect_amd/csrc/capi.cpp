@@ -1389,10 +1389,21 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
         a.reads_per_wave = 4;
         while(a.reads_per_wave < 64 && (n + a.reads_per_wave - 1) / a.reads_per_wave > resident) a.reads_per_wave *= 2;
     }
+    int rpw_forced = 0;
     if(const char* e = std::getenv("LRSC_READS_PER_WAVE")) {
         const int v = std::atoi(e);
-        if(v >= 1 && v <= 64 && (v & (v - 1)) == 0) a.reads_per_wave = (uint32_t)v;
+        if(v >= 1 && v <= 64 && (v & (v - 1)) == 0) { a.reads_per_wave = (uint32_t)v; rpw_forced = v; }
     }
+    // later launches carry fewer reads: spread them over the wavefront slots again
+    auto rpw_for = [&](uint32_t count) -> uint32_t {
+        if(rpw_forced) return (uint32_t)rpw_forced;
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+        const uint32_t resident = (uint32_t)cus * 4u * a.occupancy;
+        uint32_t r = 4;
+        while(r < 64 && (count + r - 1) / r > resident) r *= 2;
+        return r;
+    };
     hipError_t e = launch_correct_plan(a, ctx->stream);
     if(e != hipSuccess) return hip_fail(e, "correct_plan");
     std::vector<ReadPlan> plan(n);
@@ -1477,19 +1488,30 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
     HIP_TRY(hipMemcpy(ro.data(), d_out.p, (size_t)n * sizeof(ReadOut), hipMemcpyDeviceToHost));
     if(!p.no_dp || a.max_walks != 0) {
         DpStage stage;
-        DevBuf<uint32_t> d_dp_index, d_parked;
-        std::vector<uint32_t> parked, dp_index(n, 0);
+        DevBuf<uint32_t> d_dp_index, d_parked, d_yielded;
+        std::vector<uint32_t> parked, yielded, dp_index(n, 0);
         std::vector<DpRequest> reqs;
         HIP_TRY(d_dp_index.reserve(n));
         HIP_TRY(d_parked.reserve(n));
+        HIP_TRY(d_yielded.reserve(n));
+        // LRSC_CORRECT_OVERLAP=1: reads that only used up their step budget go on at once, on a side stream, while the DP stage
+        // answers the parked ones.  Off by default: measured 48.0 s vs 44.1 s per Gbase -- the correction kernel is issue-bound
+        // at full load, two concurrent launches only add a second tail.
+        hipStream_t ystream = nullptr;
+        hipEvent_t y0 = nullptr, y1 = nullptr;
+        HIP_TRY(hipStreamCreateWithFlags(&ystream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreate(&y0));
+        HIP_TRY(hipEventCreate(&y1));
+        struct SideGuard { hipStream_t s; hipEvent_t a, b; ~SideGuard() { (void)hipStreamSynchronize(s); (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipStreamDestroy(s); } } guard{ystream, y0, y1};
+        const bool overlap = std::getenv("LRSC_CORRECT_OVERLAP") != nullptr;
         for(uint32_t round = 0;; ++round) {
-            parked.clear(); reqs.clear();
+            parked.clear(); yielded.clear(); reqs.clear();
             for(uint32_t i = 0; i < n; ++i) {
                 const uint32_t r = order[i];                    // keep the long-reads-first order
                 const ReadOut& o = ro[r];
                 if(o.error != 0 || o.state == kReadDone) continue;
+                if(o.state != kReadParked) { (overlap ? yielded : parked).push_back(r); continue; }
                 parked.push_back(r);
-                if(o.state != kReadParked) continue;            // yielded: just goes on in the next launch
                 DpRequest q;
                 std::memset(&q, 0, sizeof(q));
                 q.q_off = work[r].ws_off + work[r].o_dpq;
@@ -1507,20 +1529,41 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
                 dp_index[r] = (uint32_t)reqs.size();
                 reqs.push_back(q);
             }
-            if(parked.empty()) break;
-            st = stage.run(ctx, d_ws.p, reqs);
-            if(st != LRSC_OK) return st;
-            HIP_TRY(hipMemcpyAsync(d_dp_index.p, dp_index.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-            HIP_TRY(hipMemcpyAsync(d_parked.p, parked.data(), parked.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-            CorrectArgs b2 = a;
-            b2.resume = 1; b2.order = d_parked.p; b2.n_reads = (uint32_t)parked.size();
-            b2.dp_index = d_dp_index.p; b2.dp_reqs = stage.d_reqs.p; b2.dp_msa = stage.d_msa.p; b2.dp_cons = stage.d_cons.p;
-            st = timed_launch(ctx, LRSC_K_EXTEND, [&]() { return launch_correct_reads(ctx->fm, b2, ctx->stream); });
-            if(st != LRSC_OK) return st;
+            if(parked.empty() && yielded.empty()) break;
+            if(!yielded.empty()) {
+                HIP_TRY(hipMemcpyAsync(d_yielded.p, yielded.data(), yielded.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ystream));
+                CorrectArgs by = a;
+                by.resume = 1; by.order = d_yielded.p; by.n_reads = (uint32_t)yielded.size();
+                by.reads_per_wave = rpw_for(by.n_reads);
+                by.ctr = nullptr;                               // the main stream's launches own the statistics counters
+                HIP_TRY(hipEventRecord(y0, ystream));
+                hipError_t ey = launch_correct_reads(ctx->fm, by, ystream);
+                if(ey != hipSuccess) return hip_fail(ey, "correct_reads (yielded)");
+                HIP_TRY(hipEventRecord(y1, ystream));
+            }
+            if(!parked.empty()) {
+                st = stage.run(ctx, d_ws.p, reqs);
+                if(st != LRSC_OK) return st;
+                HIP_TRY(hipMemcpyAsync(d_dp_index.p, dp_index.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+                HIP_TRY(hipMemcpyAsync(d_parked.p, parked.data(), parked.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+                CorrectArgs b2 = a;
+                b2.resume = 1; b2.order = d_parked.p; b2.n_reads = (uint32_t)parked.size();
+                b2.reads_per_wave = rpw_for(b2.n_reads);
+                b2.dp_index = d_dp_index.p; b2.dp_reqs = stage.d_reqs.p; b2.dp_msa = stage.d_msa.p; b2.dp_cons = stage.d_cons.p;
+                st = timed_launch(ctx, LRSC_K_EXTEND, [&]() { return launch_correct_reads(ctx->fm, b2, ctx->stream); });
+                if(st != LRSC_OK) return st;
+            }
+            if(!yielded.empty()) {
+                HIP_TRY(hipEventSynchronize(y1));
+                float ms = 0.f;
+                HIP_TRY(hipEventElapsedTime(&ms, y0, y1));
+                ctx->stats[LRSC_K_EXTEND].launches += 1;
+                ctx->stats[LRSC_K_EXTEND].total_ms += ms;       // overlaps the DP stage: the stage times no longer add up to wall time
+            }
             HIP_TRY(hipMemcpy(ro.data(), d_out.p, (size_t)n * sizeof(ReadOut), hipMemcpyDeviceToHost));
             if(std::getenv("LRSC_CORRECT_PROFILE"))
-                std::fprintf(stderr, "[lrsc] DP round %u: %zu reads in flight, %zu DP requests, %llu strings aligned\n", round, parked.size(),
-                             reqs.size(), (unsigned long long)stage.n_strings);
+                std::fprintf(stderr, "[lrsc] DP round %u: %zu parked + %zu yielded reads, %zu DP requests, %llu strings aligned\n", round,
+                             parked.size(), yielded.size(), reqs.size(), (unsigned long long)stage.n_strings);
         }
     }
     a.n_reads = n;
