@@ -816,8 +816,11 @@ extern "C" int lrsc_batch_kmer_grid(lrsc_ctx* ctx, lrsc_batch* b)
     // lines in flight per wavefront and this kernel is latency/MLP-bound (profiles/).
     const char* mode = std::getenv("LRSC_GRID_MODE");
     const bool quad = !ctx->fm.wide && mode && std::strcmp(mode, "quad") == 0;
+    const bool coop = !ctx->fm.wide && mode && std::strcmp(mode, "coop") == 0;
     st = timed_launch(ctx, LRSC_K_GRID, [&]() {
-        return quad ? launch_kmer_grid_quad(ctx->fm, a, ctx->d_ctr, ctx->stream) : launch_kmer_grid(ctx->fm, a, ctx->d_ctr, ctx->stream);
+        return quad ? launch_kmer_grid_quad(ctx->fm, a, ctx->d_ctr, ctx->stream)
+             : coop ? launch_kmer_grid_coop(ctx->fm, a, ctx->d_ctr, ctx->stream)
+                    : launch_kmer_grid(ctx->fm, a, ctx->d_ctr, ctx->stream);
     });
     if(st == LRSC_OK) b->grid_done = true;
     return st;
