@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void find_kmers_kernel(FmIndexDev fm, const ui
 }
 
 template <bool WIDE>
-__global__ __launch_bounds__(256) void kmer_grid_kernel(FmIndexDev fm, GridArgs a, DevCounters* ctr)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void kmer_grid_kernel(FmIndexDev fm, GridArgs a, DevCounters* ctr)
 {
     using P = typename Lay<WIDE>::pos_t;
     __shared__ __attribute__((aligned(16))) uint32_t mtab[MaskTabSize<WIDE>::value];
