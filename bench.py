@@ -65,10 +65,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; there is no CPU fallback for the product path")
+    # LRSC_BENCH_ONE_DEVICE=1: rehearsal of the multi-rank path on a one-GPU box (every rank on device 0, gloo for the barrier)
+    one_device = os.environ.get("LRSC_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if one_device:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from longreadselfcorrect_amd import Lrsc
     from longreadselfcorrect_amd import dist as lrdist
@@ -154,7 +161,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     # max over ranks of the elapsed time; sum over ranks of the bases processed
-    elapsed_max, total_bases = lrdist.combine(elapsed, float(my_bases), device="cuda")
+    elapsed_max, total_bases = lrdist.combine(elapsed, float(my_bases), device="cpu" if one_device else "cuda")
 
     st = ctx.stats(K_GRID)
     st_seeds = ctx.stats(K_SEEDS)
