@@ -587,3 +587,32 @@ def test_wide_layout_whole_path(api, wide_index, oracle, small_ds, nodp):
     p = api.params_default(5, 90)
     p.no_dp = nodp
     _check_whole_path(api, wide_index, oracle, small_ds, p, min_fm=300, min_dp=0 if nodp else 20)
+
+
+@pytest.mark.parametrize("nodp", [1, 0])
+def test_whole_path_ragged_and_foreign_reads(api, gpu_index, oracle, small_ds, nodp):
+    """The whole per-read path on awkward inputs: reads shorter than k, one base, absent from the index, homopolymers, a chimera
+    with a long unseeded stretch (a long DP query), duplicated halves -- FASTA and counters identical to the oracle."""
+    from oracle.oracle_py import pack_reads
+
+    rng = np.random.default_rng(23)
+    real = small_ds.reads
+    foreign = "".join(rng.choice(list("ACGT"), size=900))
+    chimera = real[2][:400] + foreign[:600] + real[5][200:900] + "A" * 40 + real[7][:300]
+    reads = ["ACGT", real[0][:16], real[0][:19], real[1][:60], foreign, chimera, "A" * 300, "AC" * 200, real[3], real[4][100:101],
+             real[6][:500] + real[6][:500], real[8], real[9][:1200], real[10][300:]]
+    bases, off = pack_reads(reads)
+    p = api.params_default(5, 90)
+    p.no_dp = nodp
+    ob, orb = oracle.bwt_load(small_ds.prefix + ".bwt"), oracle.bwt_load(small_ds.prefix + ".rbwt")
+    want = oracle.correct_reads(ob, orb, p, bases, off)
+    ctx = gpu_index.ctx(p, 0)
+    results, pieces = ctx.correct_reads(bases, off)
+    ctx.close()
+    cfa, dfa = _fasta(results, pieces, reads, 0)
+    assert cfa == want.correct_fa and dfa == want.discard_fa
+    names = ("total_reads_len", "corrected_len", "total_seed_num", "total_walk_num", "high_error_num", "exceed_depth_num",
+             "exceed_leave_num", "fm_num", "dp_num", "seed_dis", "merge")
+    np.testing.assert_array_equal(np.array([[getattr(r, n) for n in names] for r in results], dtype=np.int64), want.counters)
+    assert want.counters[:, 10].sum() >= 5 and (want.counters[:, 10] == 0).sum() >= 5        # corrected and discarded reads both occur
+    want.close(); ob.close(); orb.close()

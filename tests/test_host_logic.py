@@ -129,3 +129,33 @@ def test_introsort_emulation_matches_std_sort_order(api, ref, oracle, n):
         for k, w in zip(uniq, want):
             got = perm[keys[perm] == k]
             np.testing.assert_array_equal(got, w, err_msg=f"n={n} shape={shape} key={k}")
+
+
+def test_ctypes_structs_match_the_c_header(tmp_path):
+    """Every struct of include/lrsc.h that capi.py mirrors has the same size and field offsets when the header is compiled as C."""
+    import ctypes as C
+    import subprocess
+
+    from longreadselfcorrect_amd import capi
+
+    pairs = {"lrsc_interval": capi.Interval, "lrsc_biinterval": capi.BiInterval, "lrsc_rank_query": capi.RankQuery,
+             "lrsc_index_info": capi.IndexInfo, "lrsc_params": capi.Params, "lrsc_walk_desc": capi.WalkDesc,
+             "lrsc_walk_result": capi.WalkResult, "lrsc_read_result": capi.ReadResult, "lrsc_kernel_stats": capi.KernelStats,
+             "lrsc_dp_job": capi.DpJob, "lrsc_dp_result": capi.DpResult, "lrsc_msa_query": capi.MsaQuery, "lrsc_msa_result": capi.MsaResult}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "lrsc.h"', "int main(void) {"]
+    for cname, ct in pairs.items():
+        lines.append(f'printf("{cname} %zu", sizeof({cname}));')
+        for fname, _ in ct._fields_:
+            lines.append(f'printf(" %zu", offsetof({cname}, {fname}));')
+        lines.append('printf("\\n");')
+    lines += ["return 0; }"]
+    src = tmp_path / "abi.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-std=c99", f"-I{REPO / 'include'}", str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.strip().split("\n")
+    for line, (cname, ct) in zip(out, pairs.items()):
+        got = [int(x) for x in line.split()[1:]]
+        want = [C.sizeof(ct)] + [getattr(ct, f).offset for f, _ in ct._fields_]
+        assert got == want, (cname, got, want)
+    assert capi.SEED_DTYPE.itemsize == 32        # lrsc_seed: 8 x int32
