@@ -1476,6 +1476,7 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
 
     // With the DP fallback on, a read runs at most max_walks walks per launch: a round then lasts about as long as
     // max_walks walks instead of as long as the luckiest read's failure-free stretch, and parked reads get their answer sooner.
+    a.profile = std::getenv("LRSC_CORRECT_PROFILE") ? 1u : 0u;
     a.setup_quorum_pct = 40;
     if(const char* e = std::getenv("LRSC_CORRECT_QUORUM")) a.setup_quorum_pct = (uint32_t)std::min(100, std::max(0, std::atoi(e)));
     a.max_walks = p.no_dp ? 0u : 64u;

@@ -64,6 +64,7 @@ struct CorrectArgs {
     int32_t start_kmer_len, next_target, split, no_dp;
     // second and later launches: reads parked on a DP request pick up the answer
     uint32_t resume;
+    uint32_t profile;                // per-phase tick counters in ReadOut::cyc (LRSC_CORRECT_PROFILE)
     uint32_t setup_quorum_pct;       // lanes of a wavefront (in %) that must be between walks before they set the next ones up
     uint32_t max_steps;              // ... or extension steps: no new walk is started past this budget
     uint32_t max_walks;              // walks a read may run per launch before it yields (0 = no limit); keeps DP rounds even

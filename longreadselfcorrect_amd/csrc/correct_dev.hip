@@ -82,6 +82,7 @@ __global__ __launch_bounds__(64, OCC) void correct_reads_kernel(FmIndexDev fm, C
             uint32_t* best = reinterpret_cast<uint32_t*>(ws + rw.o_best);
             W.q = q;
             W.n_rank = 0; W.n_blk = 0; W.steps = R.steps; W.error = 0; W.cyc_setup = R.cyc[1]; W.cyc_loop = R.cyc[2];
+            W.profile = a.profile != 0;
             uint8_t* dpq = ws + rw.o_dpq;                                          // the parked DP query lives here between launches
 
             // source = pieceVec.back(): the SeedFeature fields the loop reads (SeedFeature.h:22-45)

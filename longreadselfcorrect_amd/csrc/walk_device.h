@@ -506,6 +506,7 @@ struct Walk {
     }
 
     bool ended;                        // the frontier overflowed maxLeaves: the loop ends after this isTerminated
+    bool profile = false;              // per-step tick counters on (LRSC_CORRECT_PROFILE)
 
     __device__ __noinline__ void begin()
     {
@@ -574,9 +575,12 @@ struct Walk {
     __device__ bool step()
     {
         if(ended || error || !(n_cur != 0 && n_cur <= maxLeaves && currentLength <= maxLength)) return false;
-        const uint64_t t_step0 = __builtin_readcyclecounter();
-        step_body();
-        cyc_loop += __builtin_readcyclecounter() - t_step0;
+        if(profile) {                                    // two s_memtime round trips per step are not free: only when asked for
+            const uint64_t t_step0 = __builtin_readcyclecounter();
+            step_body();
+            cyc_loop += __builtin_readcyclecounter() - t_step0;
+        } else
+            step_body();
         return true;
     }
 
