@@ -1476,6 +1476,18 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
 
     // With the DP fallback on, a read runs at most max_walks walks per launch: a round then lasts about as long as
     // max_walks walks instead of as long as the luckiest read's failure-free stretch, and parked reads get their answer sooner.
+    // LRSC_CORRECT_QUEUE=k (experimental): launch 1/k of the lanes and let every lane pull reads from a queue.  Off: with 100k
+    // reads it trades resident wavefronts for lane refill and loses (39.9 - 46.6 s vs 32.2 s per Gbase, default flow).
+    DevBuf<uint32_t> d_queue;
+    uint32_t queue_rpl = 0;
+    if(const char* e = std::getenv("LRSC_CORRECT_QUEUE")) queue_rpl = (uint32_t)std::max(0, std::atoi(e));
+    if(queue_rpl) HIP_TRY(d_queue.reserve(1));
+    auto with_queue = [&](CorrectArgs& x) -> hipError_t {
+        if(!queue_rpl) return hipSuccess;
+        x.queue = d_queue.p;
+        x.queue_waves = std::max<uint32_t>(1, (x.n_reads + x.reads_per_wave * queue_rpl - 1) / (x.reads_per_wave * queue_rpl));
+        return hipMemsetAsync(d_queue.p, 0, sizeof(uint32_t), ctx->stream);
+    };
     a.profile = std::getenv("LRSC_CORRECT_PROFILE") ? 1u : 0u;
     a.setup_quorum_pct = 40;
     if(const char* e = std::getenv("LRSC_CORRECT_QUORUM")) a.setup_quorum_pct = (uint32_t)std::min(100, std::max(0, std::atoi(e)));
@@ -1483,6 +1495,7 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
     a.max_steps = 2000;
     if(const char* e = std::getenv("LRSC_CORRECT_MAX_WALKS")) a.max_walks = (uint32_t)std::max(0, std::atoi(e));
     if(const char* e = std::getenv("LRSC_CORRECT_MAX_STEPS")) a.max_steps = (uint32_t)std::max(1, std::atoi(e));
+    HIP_TRY(with_queue(a));
     int st = timed_launch(ctx, LRSC_K_EXTEND, [&]() { return launch_correct_reads(ctx->fm, a, ctx->stream); });
     if(st != LRSC_OK) return st;
 
@@ -1554,6 +1567,7 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
                 b2.resume = 1; b2.order = d_parked.p; b2.n_reads = (uint32_t)parked.size();
                 b2.reads_per_wave = rpw_for(b2.n_reads);
                 b2.dp_index = d_dp_index.p; b2.dp_reqs = stage.d_reqs.p; b2.dp_msa = stage.d_msa.p; b2.dp_cons = stage.d_cons.p;
+                HIP_TRY(with_queue(b2));
                 st = timed_launch(ctx, LRSC_K_EXTEND, [&]() { return launch_correct_reads(ctx->fm, b2, ctx->stream); });
                 if(st != LRSC_OK) return st;
             }

@@ -64,6 +64,8 @@ struct CorrectArgs {
     int32_t start_kmer_len, next_target, split, no_dp;
     // second and later launches: reads parked on a DP request pick up the answer
     uint32_t resume;
+    uint32_t* queue;                 // optional work queue (zeroed before the launch): next slot of `order` to hand out
+    uint32_t queue_waves;            // wavefronts to launch when the queue is used
     uint32_t profile;                // per-phase tick counters in ReadOut::cyc (LRSC_CORRECT_PROFILE)
     uint32_t setup_quorum_pct;       // lanes of a wavefront (in %) that must be between walks before they set the next ones up
     uint32_t max_steps;              // ... or extension steps: no new walk is started past this budget

@@ -21,10 +21,15 @@ __global__ __launch_bounds__(64, OCC) void correct_reads_kernel(FmIndexDev fm, C
     __shared__ __attribute__((aligned(16))) uint32_t mtab[MaskTabSize<WIDE>::value];
     init_mask_table<WIDE>(mtab);
     const uint32_t stride = 64u / a.reads_per_wave;
-    const uint32_t slot = blockIdx.x * a.reads_per_wave + threadIdx.x / stride;
+    const uint32_t slot0 = blockIdx.x * a.reads_per_wave + threadIdx.x / stride;
     const bool owner = (threadIdx.x % stride) == 0;
     uint32_t n_rank = 0, n_blk = 0;
-    if(owner && slot < a.n_reads) {
+    // a.queue set: fewer lanes than reads, every lane pulls the next read of the launch when its current one is done,
+    // parked or out of budget (the lanes of a wavefront then stay busy until the queue is empty)
+    for(uint32_t slot = slot0, first = 1; owner; first = 0) {
+        if(a.queue) slot = atomicAdd(a.queue, 1u);
+        else if(!first) break;
+        if(slot >= a.n_reads) break;
         const uint32_t r = a.order ? a.order[slot] : slot;
         const ReadWork rw = a.work[r];
         ReadOut& R = a.out[r];
@@ -296,7 +301,7 @@ __global__ __launch_bounds__(64, OCC) void correct_reads_kernel(FmIndexDev fm, C
                 it += 1;
                 next = 0;
             }
-            n_rank = W.n_rank; n_blk = W.n_blk;
+            n_rank += W.n_rank; n_blk += W.n_blk;
             R.steps = W.steps;
             cyc_stitch = __builtin_readcyclecounter() - t_all0 - (cyc_prep - R.cyc[0]) - (W.cyc_setup - R.cyc[1]) - (W.cyc_loop - R.cyc[2]);
             R.cyc[1] = W.cyc_setup; R.cyc[2] = W.cyc_loop;
@@ -364,7 +369,8 @@ hipError_t launch_correct_reads(const FmIndexDev& fm, const CorrectArgs& a, hipS
 {
     if(a.n_reads == 0) return hipSuccess;
     if(a.reads_per_wave == 0 || a.reads_per_wave > 64 || (a.reads_per_wave & (a.reads_per_wave - 1))) return hipErrorInvalidValue;
-    const unsigned nb = (a.n_reads + a.reads_per_wave - 1) / a.reads_per_wave;
+    unsigned nb = (a.n_reads + a.reads_per_wave - 1) / a.reads_per_wave;
+    if(a.queue && a.queue_waves != 0 && nb > a.queue_waves) nb = a.queue_waves;
     if(a.occupancy >= 4) {
         if(fm.wide) hipLaunchKernelGGL((correct_reads_kernel<true, 4>), dim3(nb), dim3(64), 0, stream, fm, a);
         else        hipLaunchKernelGGL((correct_reads_kernel<false, 4>), dim3(nb), dim3(64), 0, stream, fm, a);
