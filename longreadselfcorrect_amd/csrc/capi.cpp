@@ -1148,7 +1148,7 @@ struct DpStage {
             r.w_cols = dp_msa_columns(r.lq);
             r.cons_off = cons_total;
             cons_total += r.cons_cap;
-            if(((r.lq + 2 + 3) & ~3u) + r.str_cap + 8 > 64 * 1024) return fail(LRSC_ERR_UNSUPPORTED, "dp request: query longer than ~30 kb");
+            if(((r.lq + 2 + 3) & ~3u) + 264 + r.str_cap + 16 > 64 * 1024) return fail(LRSC_ERR_UNSUPPORTED, "dp request: query longer than ~30 kb");
         }
         HIP_TRY(d_reqs.reserve(n));
         HIP_TRY(d_msa.reserve(n));
@@ -1660,7 +1660,7 @@ extern "C" int lrsc_dp_align(lrsc_ctx* ctx, const char* seq, uint64_t seq_len, c
         ops_total += (uint64_t)j.s1_len + j.s2_len + 1;
         max1 = std::max(max1, j.s1_len); max2 = std::max(max2, j.s2_len);
     }
-    if(((max1 + 2 + 3) & ~3u) + max2 + 8 > 64 * 1024) return fail(LRSC_ERR_UNSUPPORTED, "dp job: s1 + s2 must fit the 64 KB LDS stage");
+    if(((max1 + 2 + 3) & ~3u) + 264 + ((max2 + 3) & ~3u) + 16 > 64 * 1024) return fail(LRSC_ERR_UNSUPPORTED, "dp job: s1 + s2 must fit the 64 KB LDS stage");
     const uint32_t n_waves = std::min<uint32_t>(dp_wave_count(ctx), n);
     DevBuf<uint8_t> d_codes, d_ops, d_trace;
     DevBuf<DpJob> d_jobs;

@@ -20,6 +20,7 @@ namespace lrsc {
 namespace {
 constexpr int kNeg = -(1 << 29);
 constexpr int kIntMin = -2147483647 - 1;
+constexpr uint32_t kS2Pad = 264;
 
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
@@ -47,7 +48,11 @@ __global__ __launch_bounds__(64) void dp_align_kernel(DpAlignArgs a)
 {
     extern __shared__ uint8_t smem[];
     uint8_t* S1 = smem;                                        // s1 codes, S1[L1] = 4 (the string's NUL)
-    uint8_t* S2 = smem + ((a.max_s1 + 2 + 3) & ~3u);           // s2 codes, S2[L2..L2+4] = 4
+    // s2 codes at S2[0 .. L2), sentinel 4 in the kS2Pad bytes before and the 16 after: a lane's five characters
+    // s2[j-1 .. j+3] are then two aligned dword reads for any band position
+    uint8_t* S2buf = smem + ((a.max_s1 + 2 + 3) & ~3u);
+    uint8_t* S2 = S2buf + kS2Pad;
+    for(uint32_t i = threadIdx.x; i < kS2Pad; i += 64) S2buf[i] = 4;
     const uint32_t lane = threadIdx.x;
     uint8_t* trace = a.trace + (uint64_t)blockIdx.x * a.trace_stride;
     const int half = (int)a.band_width / 2;
@@ -68,7 +73,7 @@ __global__ __launch_bounds__(64) void dp_align_kernel(DpAlignArgs a)
         const int L1 = (int)J.s1_len, L2 = (int)J.s2_len;
         __syncthreads();
         for(int i = (int)lane; i <= L1; i += 64) S1[i] = i < L1 ? a.codes[J.s1_off + i] : (uint8_t)4;
-        for(int j = (int)lane; j <= L2 + 4; j += 64) S2[j] = j < L2 ? a.strings[J.s2_off + j] : (uint8_t)4;
+        for(int j = (int)lane; j < L2 + 16; j += 64) S2[j] = j < L2 ? a.strings[J.s2_off + j] : (uint8_t)4;
         __syncthreads();
         if(J.mode != 0 && L2 >= L1) {                              // identical sequence from the forward / backward extension
             const int shift = J.mode == 1 ? 0 : L2 - L1;
@@ -98,10 +103,14 @@ __global__ __launch_bounds__(64) void dp_align_kernel(DpAlignArgs a)
                 const uint32_t c1 = S1[i - 1];
                 const bool h1 = c1 == S1[i];
                 uint32_t s2c[5];
+                {
+                    int idx = jbase + r0 - 1;                               // >= -kS2Pad whenever the column is computed
+                    idx = idx > L2 + 8 ? L2 + 8 : idx;                      // rows past the end are out of range anyway
+                    const uint32_t b = (uint32_t)(idx + (int)kS2Pad);
+                    const uint32_t* p32 = reinterpret_cast<const uint32_t*>(S2buf + (b & ~3u));
+                    const unsigned long long v = (((unsigned long long)p32[1] << 32) | p32[0]) >> (8u * (b & 3u));
 #pragma unroll
-                for(int t = 0; t < 5; ++t) {
-                    const int idx = jbase + r0 + t - 1;
-                    s2c[t] = (idx >= 0 && idx <= L2 + 4) ? S2[idx] : 4u;
+                    for(int t = 0; t < 5; ++t) s2c[t] = (uint32_t)(v >> (8 * t)) & 0xFFu;
                 }
                 int diag[4], leftg[4], B[4];
                 bool inr[4], left_in[4];
@@ -127,7 +136,6 @@ __global__ __launch_bounds__(64) void dp_align_kernel(DpAlignArgs a)
                 const int below = lane_below(0, cur[3]);            // band row r0 - 1 of this column
 #pragma unroll
                 for(int t = 0; t < 4; ++t) {
-                    if(!inr[t]) continue;
                     const int r = r0 + t;
                     const int curr = cur[t];
                     const bool eq_diag = curr == diag[t];
@@ -139,7 +147,7 @@ __global__ __launch_bounds__(64) void dp_align_kernel(DpAlignArgs a)
                     else if(h1) dir = eq_left ? 3u : eq_up ? 2u : 0u;
                     else dir = eq_diag ? 0u : eq_left ? 3u : 2u;
                     if(dir == 0u && c1 != s2c[t]) dir = 1u;         // M over a mismatch
-                    flags |= dir << (2 * t);
+                    flags |= inr[t] ? dir << (2 * t) : 0u;
                 }
             }
             trace[(uint64_t)i * kDpTraceStride + lane] = (uint8_t)flags;
@@ -230,7 +238,7 @@ hipError_t launch_dp_align(const DpAlignArgs& a, uint32_t n_waves, hipStream_t s
 {
     if(a.n_jobs == 0) return hipSuccess;
     if(a.band_width < 2 || (a.band_width / 2) * 2 + 1 > kDpMaxBand) return hipErrorInvalidValue;
-    const size_t lds = ((a.max_s1 + 2 + 3) & ~3u) + a.max_s2 + 8;
+    const size_t lds = ((a.max_s1 + 2 + 3) & ~3u) + kS2Pad + ((a.max_s2 + 3) & ~3u) + 16;
     if(lds > 64 * 1024) return hipErrorInvalidValue;
     if(n_waves > a.n_jobs) n_waves = a.n_jobs;
     hipLaunchKernelGGL(dp_align_kernel, dim3(n_waves), dim3(64), lds, stream, a);
