@@ -214,12 +214,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             if(lean) {
                 const uint32_t c = w[s];
                 if(!st.fwd_broken) {
-                    st.fwd = update_interval<WIDE>(sf, c, st.fwd, mtab, st.n_blk);
+                    st.fwd = update_interval<WIDE, false>(sf, c, st.fwd, mtab, st.n_blk);
                     st.fwd_broken = st.fwd.lo > st.fwd.hi;
                     st.n_rank += 2;
                 }
                 if(!st.rvc_broken) {
-                    st.rvc = update_interval<WIDE>(sr, 3u - c, st.rvc, mtab, st.n_blk);
+                    st.rvc = update_interval<WIDE, false>(sr, 3u - c, st.rvc, mtab, st.n_blk);
                     st.rvc_broken = st.rvc.lo > st.rvc.hi;
                     st.n_rank += 2;
                 }

@@ -212,7 +212,10 @@ template <class P> struct IvT { P lo, hi; };   // lower, upper; upper stored as-
 
 // BWTAlgorithms::updateInterval (BWTAlgorithms.h:66-72) on one strand.  The second block is only
 // loaded when the two rank positions straddle a block boundary.
-template <bool WIDE>
+// FAST2: take the shared-match-words path when both rank positions fall in one block.  It pays where few lanes of a
+// wavefront are active (the correction kernel); in the position-parallel grid kernel some lane nearly always straddles
+// a block boundary, both branches would run, and the branch-free form is cheaper.
+template <bool WIDE, bool FAST2 = true>
 __device__ __forceinline__ IvT<typename Lay<WIDE>::pos_t> update_interval(const StrandC<typename Lay<WIDE>::pos_t>& s, uint32_t code,
                                                                           IvT<typename Lay<WIDE>::pos_t> iv,
                                                                           const uint32_t* __restrict__ mtab, uint32_t& n_blk)
@@ -226,12 +229,13 @@ __device__ __forceinline__ IvT<typename Lay<WIDE>::pos_t> update_interval(const 
     typename L::Regs ra, rb;
     L::load(s.blocks, bl, ra);
     uint64_t ca, cb;
-    if(bu == bl) {
+    if(FAST2 && bu == bl) {
         // both rank positions in one block (the rule once an interval is small): match words once, two masked popcounts
         L::count2(ra, code, mtab + ol * L::kRow, mtab + ou * L::kRow, ca, cb);
         rb = ra;
     } else {
-        L::load(s.blocks, bu, rb);
+        rb = ra;
+        if(bu != bl) L::load(s.blocks, bu, rb);
         ca = L::count(ra, code, mtab + ol * L::kRow);
         cb = L::count(rb, code, mtab + ou * L::kRow);
     }
