@@ -54,7 +54,7 @@ static int hip_fail(hipError_t e, const char* what)
 struct DeviceCopy {
     void* blocks[2] = {nullptr, nullptr};
     uint64_t* dollars[2] = {nullptr, nullptr};
-    void* ktab[4] = {nullptr, nullptr, nullptr, nullptr};
+    void* ktab[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     FmIndexDev dev{};
 };
 
@@ -288,16 +288,19 @@ extern "C" int lrsc_index_upload(lrsc_index* idx, int device)
         if(const char* e = std::getenv("LRSC_KTAB_K")) T = std::atoi(e);
         int T2 = T > 0 ? std::min(15, T + 2) : 0;
         if(const char* e = std::getenv("LRSC_KTAB_K2")) T2 = std::atoi(e);
-        uint32_t want[4] = {5, 9, (uint32_t)T, (uint32_t)T2};
-        uint32_t ks[4] = {0, 0, 0, 0};
+        // LRSC_KTAB_K3 (experimental, default off): a fifth table of T + 3 (16-mers: 69 GB)
+        int T3 = 0;
+        if(const char* e = std::getenv("LRSC_KTAB_K3")) T3 = std::atoi(e);
+        uint32_t want[5] = {5, 9, (uint32_t)T, (uint32_t)T2, (uint32_t)T3};
+        uint32_t ks[5] = {0, 0, 0, 0, 0};
         uint32_t n_t = 0;
-        for(int i = 0; i < 4 && T > 0; ++i) {
-            if(want[i] == 0 || want[i] > 15 || (n_t > 0 && want[i] <= ks[n_t - 1])) continue;
+        for(int i = 0; i < 5 && T > 0; ++i) {
+            if(want[i] == 0 || want[i] > 16 || (n_t > 0 && want[i] <= ks[n_t - 1])) continue;
             const size_t bytes = (size_t)16 << (2 * want[i]);
-            if(i == 3) {
+            if(i >= 3) {
                 size_t free_b = 0, total_b = 0;
                 HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-                if(bytes > free_b / 4) continue;
+                if(bytes > free_b / (i == 3 ? 4 : 3)) continue;
             }
             HIP_TRY(hipMalloc(&dc.ktab[n_t], bytes));
             // each table starts from the previous (smaller) one; dc.dev.ktab[].k stays 0 until all are built so that the
@@ -325,7 +328,7 @@ extern "C" void lrsc_index_close(lrsc_index* idx)
             if(kv.second.blocks[s]) (void)hipFree(kv.second.blocks[s]);
             if(kv.second.dollars[s]) (void)hipFree(kv.second.dollars[s]);
         }
-        for(int t = 0; t < 4; ++t) if(kv.second.ktab[t]) (void)hipFree(kv.second.ktab[t]);
+        for(int t = 0; t < 5; ++t) if(kv.second.ktab[t]) (void)hipFree(kv.second.ktab[t]);
     }
     delete idx;
 }

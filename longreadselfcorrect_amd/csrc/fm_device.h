@@ -66,7 +66,7 @@ struct FmStrand {
 // k-mer interval tables (device-side BWTIntervalCache, SuffixTools/BWTIntervalCache.h:24-29 -- the
 // reference has the class but pbcorrect leaves it unused): entry[code(w)] = {fwd.lo, fwd.hi, rvc.lo, rvc.hi}
 // of findBiInterval(w) INCLUDING findInterval's early exit, i.e. exactly the state after the first k
-// steps of a search.  Narrow (32-bit) indexes only.  Up to four sizes, ascending.
+// steps of a search.  Narrow (32-bit) indexes only.  Up to five sizes, ascending.
 struct KmerTable {
     const void* entries;         // uint4[4^k]
     uint32_t k;                  // 0 = absent
@@ -76,7 +76,7 @@ struct FmIndexDev {
     FmStrand strand[2];          // [LRSC_BWT], [LRSC_RBWT]
     uint32_t wide;               // 0 -> Block32, 1 -> Block64
     uint32_t pad;
-    KmerTable ktab[4];
+    KmerTable ktab[5];
 };
 
 // mask of the low n bits of a 32-symbol word, n clamped to [0, 32]

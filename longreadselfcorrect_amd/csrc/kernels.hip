@@ -15,6 +15,8 @@
 //     inherently random (BWT order), so the 64-byte block is the unit of traffic.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "kernels.h"
 #include "rank_device.h"
 
@@ -198,10 +200,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                     fwd_base_ok = kb == base_k && !tb.fwd_broken;
                     n_tab += kb != 0;
                 }
-                // slots below the table size are not stored in compact mode (freq_index < 0): check, else fall back
+                // a stored slot below the table size (freq_index >= 0) must have its own table of exactly that size
+                // (the 15-mers when the search starts from the 16-mer table): check, else fall back
                 bool ok = fwd_base_ok;
-                for(uint32_t j = 0; j < a.n_k && a.ks[j] < tk; ++j) ok = ok && (a.freq_index[j] < 0);
+                for(uint32_t j = 0; j < a.n_k && a.ks[j] < tk; ++j)
+                    if(a.freq_index[j] >= 0)
+                        ok = ok && (fm.ktab[0].k == a.ks[j] || fm.ktab[1].k == a.ks[j] || fm.ktab[2].k == a.ks[j] || fm.ktab[3].k == a.ks[j]);
                 if(ok) {
+                    for(uint32_t j = 0; j < a.n_k && a.ks[j] < tk; ++j) {
+                        if(a.freq_index[j] < 0) continue;
+                        WalkState<P> te = walk_init<P>();
+                        (void)table_start<WIDE>(fm, [&](uint32_t t) { return (uint32_t)w[t]; }, a.ks[j], te);
+                        st = te; st.counted = base_k;
+                        emit(j);
+                        n_tab += 1;
+                    }
                     st = ts; st.counted = base_k; st.n_rank = 0; st.n_blk = 0;
                     s0 = tk; n_tab += 1; lean = true;
                     while(slot < a.n_k && a.ks[slot] < tk) ++slot;
@@ -249,10 +262,10 @@ __global__ __launch_bounds__(256) void ktab_build_kernel(FmIndexDev fm, uint32_t
     using P = uint32_t;
     __shared__ __attribute__((aligned(16))) uint32_t mtab[MaskTabSize<false>::value];
     init_mask_table<false>(mtab);
-    const uint64_t code = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if(code >= (1ull << (2 * k))) return;
     const StrandC<P> sf = strand_consts<P>(fm.strand[LRSC_RBWT]);
     const StrandC<P> sr = strand_consts<P>(fm.strand[LRSC_BWT]);
+    const uint64_t n_codes = 1ull << (2 * k);
+    for(uint64_t code = (uint64_t)blockIdx.x * 256 + threadIdx.x; code < n_codes; code += (uint64_t)gridDim.x * 256) {
     WalkState<P> st = walk_init<P>();
     if(prev_k != 0) {
         const uint4 e = prev[code >> (2 * (k - prev_k))];
@@ -266,6 +279,7 @@ __global__ __launch_bounds__(256) void ktab_build_kernel(FmIndexDev fm, uint32_t
         st = walk_step<false>(sf, sr, c, 1u << 30, st, mtab);
     }
     entries[code] = make_uint4(st.fwd.lo, st.fwd.hi, st.rvc.lo, st.rvc.hi);
+    }
 }
 
 __global__ __launch_bounds__(256) void encode_kernel(const char* __restrict__ ascii, uint8_t* __restrict__ codes,
@@ -347,8 +361,8 @@ hipError_t launch_kmer_grid(const FmIndexDev& fm, const GridArgs& a, DevCounters
 
 hipError_t launch_ktab_build(const FmIndexDev& fm, uint32_t k, void* entries, uint32_t prev_k, const void* prev, hipStream_t stream)
 {
-    if(fm.wide || k == 0 || k > 15 || prev_k >= k) return hipErrorInvalidValue;
-    const uint64_t n = 1ull << (2 * k);
+    if(fm.wide || k == 0 || k > 16 || prev_k >= k) return hipErrorInvalidValue;
+    const uint64_t n = std::min<uint64_t>(1ull << (2 * k), 1ull << 30);          // grid-stride above 2^30 threads
     hipLaunchKernelGGL(ktab_build_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, fm, k, reinterpret_cast<uint4*>(entries), prev_k,
                        reinterpret_cast<const uint4*>(prev));
     return hipGetLastError();

@@ -356,10 +356,11 @@ __device__ __forceinline__ uint32_t table_start(const FmIndexDev& fm, Get get, u
     if(fm.ktab[1].k != 0 && fm.ktab[1].k <= max_k) best = 1;
     if(fm.ktab[2].k != 0 && fm.ktab[2].k <= max_k) best = 2;
     if(fm.ktab[3].k != 0 && fm.ktab[3].k <= max_k) best = 3;
+    if(fm.ktab[4].k != 0 && fm.ktab[4].k <= max_k) best = 4;
     if(best < 0) return 0;
-    const uint32_t k = best == 0 ? fm.ktab[0].k : best == 1 ? fm.ktab[1].k : best == 2 ? fm.ktab[2].k : fm.ktab[3].k;
+    const uint32_t k = best == 0 ? fm.ktab[0].k : best == 1 ? fm.ktab[1].k : best == 2 ? fm.ktab[2].k : best == 3 ? fm.ktab[3].k : fm.ktab[4].k;
     const uint4* tab = reinterpret_cast<const uint4*>(best == 0 ? fm.ktab[0].entries : best == 1 ? fm.ktab[1].entries
-                                                    : best == 2 ? fm.ktab[2].entries : fm.ktab[3].entries);
+                                                    : best == 2 ? fm.ktab[2].entries : best == 3 ? fm.ktab[3].entries : fm.ktab[4].entries);
     uint32_t code = 0;
     for(uint32_t t = 0; t < k; ++t) code = (code << 2) | get(t);
     const uint4 e = tab[code];
