@@ -281,7 +281,8 @@ extern "C" int lrsc_index_upload(lrsc_index* idx, int device)
     // to [9, 13] -- up to there practically every k-mer occurs in the index -- and T + 2, where most chance matches have
     // died (16 bytes x 4^k: 1.07 GB at 13, 17.2 GB at 15, taken only if it fits a quarter of the free HBM).
     // LRSC_KTAB_K overrides T (0 disables all tables), LRSC_KTAB_K2 the fourth size (0 disables it).
-    if(!idx->wide) {
+    {
+        const size_t entry_bytes = idx->wide ? 32 : 16;          // 4 x u64 for Block64 indexes
         int T = 0;
         for(uint64_t n = idx->num_symbols; n >= 4; n >>= 2) ++T;
         T = std::max(9, std::min(13, T));
@@ -296,7 +297,7 @@ extern "C" int lrsc_index_upload(lrsc_index* idx, int device)
         uint32_t n_t = 0;
         for(int i = 0; i < 5 && T > 0; ++i) {
             if(want[i] == 0 || want[i] > 16 || (n_t > 0 && want[i] <= ks[n_t - 1])) continue;
-            const size_t bytes = (size_t)16 << (2 * want[i]);
+            const size_t bytes = entry_bytes << (2 * want[i]);
             if(i >= 3) {
                 size_t free_b = 0, total_b = 0;
                 HIP_TRY(hipMemGetInfo(&free_b, &total_b));

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         // counter is base_k), and (b) a strand that went empty needs no further Occ queries at all.
         uint32_t s0 = 0;
         bool lean = false;
-        if(!WIDE && !a.out_iv && !a.out_size && !a.out_count && !a.slot_iv) {
+        if(!a.out_iv && !a.out_size && !a.out_count && !a.slot_iv) {
             WalkState<P> ts = st;
             const uint32_t tk = table_start<WIDE>(fm, [&](uint32_t t) { return (uint32_t)w[t]; }, avail, ts);
             if(tk >= base_k) {
@@ -254,31 +254,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     flush_counters(ctr, n_rank, n_blk, n_tab);
 }
 
-// every k-mer's findBiInterval (with early exit) -> table entry; narrow layout only.  A smaller table that is already
-// built (prev_k < k) supplies the state after the first prev_k characters.
+// every k-mer's findBiInterval (with early exit) -> table entry (4 x u32 for narrow indexes, 4 x u64 for wide ones).  A smaller
+// table that is already built (prev_k < k) supplies the state after the first prev_k characters.
+template <bool WIDE>
 __global__ __launch_bounds__(256) void ktab_build_kernel(FmIndexDev fm, uint32_t k, uint4* __restrict__ entries, uint32_t prev_k,
                                                          const uint4* __restrict__ prev)
 {
-    using P = uint32_t;
-    __shared__ __attribute__((aligned(16))) uint32_t mtab[MaskTabSize<false>::value];
-    init_mask_table<false>(mtab);
+    using P = typename Lay<WIDE>::pos_t;
+    __shared__ __attribute__((aligned(16))) uint32_t mtab[MaskTabSize<WIDE>::value];
+    init_mask_table<WIDE>(mtab);
     const StrandC<P> sf = strand_consts<P>(fm.strand[LRSC_RBWT]);
     const StrandC<P> sr = strand_consts<P>(fm.strand[LRSC_BWT]);
     const uint64_t n_codes = 1ull << (2 * k);
     for(uint64_t code = (uint64_t)blockIdx.x * 256 + threadIdx.x; code < n_codes; code += (uint64_t)gridDim.x * 256) {
-    WalkState<P> st = walk_init<P>();
-    if(prev_k != 0) {
-        const uint4 e = prev[code >> (2 * (k - prev_k))];
-        st.fwd.lo = e.x; st.fwd.hi = e.y; st.rvc.lo = e.z; st.rvc.hi = e.w;
-        st.fwd_broken = e.x > e.y; st.rvc_broken = e.z > e.w;
-        st.size = prev_k;
-    }
-    for(uint32_t t = prev_k; t < k; ++t) {
-        if(st.fwd_broken && st.rvc_broken) break;
-        const uint32_t c = (uint32_t)(code >> (2 * (k - 1 - t))) & 3u;
-        st = walk_step<false>(sf, sr, c, 1u << 30, st, mtab);
-    }
-    entries[code] = make_uint4(st.fwd.lo, st.fwd.hi, st.rvc.lo, st.rvc.hi);
+        WalkState<P> st = walk_init<P>();
+        if(prev_k != 0) {
+            const uint64_t pc = code >> (2 * (k - prev_k));
+            if(WIDE) {
+                const uint4 a = prev[pc * 2], b = prev[pc * 2 + 1];
+                st.fwd.lo = (P)(((uint64_t)a.y << 32) | a.x); st.fwd.hi = (P)(((uint64_t)a.w << 32) | a.z);
+                st.rvc.lo = (P)(((uint64_t)b.y << 32) | b.x); st.rvc.hi = (P)(((uint64_t)b.w << 32) | b.z);
+            } else {
+                const uint4 e = prev[pc];
+                st.fwd.lo = (P)e.x; st.fwd.hi = (P)e.y; st.rvc.lo = (P)e.z; st.rvc.hi = (P)e.w;
+            }
+            st.fwd_broken = st.fwd.lo > st.fwd.hi; st.rvc_broken = st.rvc.lo > st.rvc.hi;
+            st.size = prev_k;
+        }
+        for(uint32_t t = prev_k; t < k; ++t) {
+            if(st.fwd_broken && st.rvc_broken) break;
+            const uint32_t c = (uint32_t)(code >> (2 * (k - 1 - t))) & 3u;
+            st = walk_step<WIDE>(sf, sr, c, 1u << 30, st, mtab);
+        }
+        if(WIDE) {
+            const uint64_t fl = (uint64_t)st.fwd.lo, fh = (uint64_t)st.fwd.hi, rl = (uint64_t)st.rvc.lo, rh = (uint64_t)st.rvc.hi;
+            entries[code * 2] = make_uint4((uint32_t)fl, (uint32_t)(fl >> 32), (uint32_t)fh, (uint32_t)(fh >> 32));
+            entries[code * 2 + 1] = make_uint4((uint32_t)rl, (uint32_t)(rl >> 32), (uint32_t)rh, (uint32_t)(rh >> 32));
+        } else
+            entries[code] = make_uint4((uint32_t)st.fwd.lo, (uint32_t)st.fwd.hi, (uint32_t)st.rvc.lo, (uint32_t)st.rvc.hi);
     }
 }
 
@@ -361,10 +374,12 @@ hipError_t launch_kmer_grid(const FmIndexDev& fm, const GridArgs& a, DevCounters
 
 hipError_t launch_ktab_build(const FmIndexDev& fm, uint32_t k, void* entries, uint32_t prev_k, const void* prev, hipStream_t stream)
 {
-    if(fm.wide || k == 0 || k > 16 || prev_k >= k) return hipErrorInvalidValue;
+    if(k == 0 || k > 16 || prev_k >= k) return hipErrorInvalidValue;
     const uint64_t n = std::min<uint64_t>(1ull << (2 * k), 1ull << 30);          // grid-stride above 2^30 threads
-    hipLaunchKernelGGL(ktab_build_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, fm, k, reinterpret_cast<uint4*>(entries), prev_k,
-                       reinterpret_cast<const uint4*>(prev));
+    if(fm.wide) hipLaunchKernelGGL(ktab_build_kernel<true>, dim3(blocks_for(n)), dim3(256), 0, stream, fm, k, reinterpret_cast<uint4*>(entries), prev_k,
+                                   reinterpret_cast<const uint4*>(prev));
+    else        hipLaunchKernelGGL(ktab_build_kernel<false>, dim3(blocks_for(n)), dim3(256), 0, stream, fm, k, reinterpret_cast<uint4*>(entries), prev_k,
+                                   reinterpret_cast<const uint4*>(prev));
     return hipGetLastError();
 }
 

@@ -349,7 +349,6 @@ template <bool WIDE, class Get>
 __device__ __forceinline__ uint32_t table_start(const FmIndexDev& fm, Get get, uint32_t max_k,
                                                 WalkState<typename Lay<WIDE>::pos_t>& st)
 {
-    if(WIDE) return 0;
     using P = typename Lay<WIDE>::pos_t;
     int best = -1;
     if(fm.ktab[0].k != 0 && fm.ktab[0].k <= max_k) best = 0;
@@ -359,12 +358,22 @@ __device__ __forceinline__ uint32_t table_start(const FmIndexDev& fm, Get get, u
     if(fm.ktab[4].k != 0 && fm.ktab[4].k <= max_k) best = 4;
     if(best < 0) return 0;
     const uint32_t k = best == 0 ? fm.ktab[0].k : best == 1 ? fm.ktab[1].k : best == 2 ? fm.ktab[2].k : best == 3 ? fm.ktab[3].k : fm.ktab[4].k;
-    const uint4* tab = reinterpret_cast<const uint4*>(best == 0 ? fm.ktab[0].entries : best == 1 ? fm.ktab[1].entries
-                                                    : best == 2 ? fm.ktab[2].entries : best == 3 ? fm.ktab[3].entries : fm.ktab[4].entries);
+    const void* tabv = best == 0 ? fm.ktab[0].entries : best == 1 ? fm.ktab[1].entries
+                     : best == 2 ? fm.ktab[2].entries : best == 3 ? fm.ktab[3].entries : fm.ktab[4].entries;
     uint32_t code = 0;
     for(uint32_t t = 0; t < k; ++t) code = (code << 2) | get(t);
-    const uint4 e = tab[code];
-    st.fwd.lo = (P)e.x; st.fwd.hi = (P)e.y; st.rvc.lo = (P)e.z; st.rvc.hi = (P)e.w;
+    // narrow indexes: 4 x u32 per entry; wide (Block64) indexes: 4 x u64
+    struct { P x, y, z, w; } e;
+    if(WIDE) {
+        const uint4* tab = reinterpret_cast<const uint4*>(tabv) + (uint64_t)code * 2;
+        const uint4 a = tab[0], b = tab[1];
+        e.x = (P)(((uint64_t)a.y << 32) | a.x); e.y = (P)(((uint64_t)a.w << 32) | a.z);
+        e.z = (P)(((uint64_t)b.y << 32) | b.x); e.w = (P)(((uint64_t)b.w << 32) | b.z);
+    } else {
+        const uint4 a = reinterpret_cast<const uint4*>(tabv)[code];
+        e.x = (P)a.x; e.y = (P)a.y; e.z = (P)a.z; e.w = (P)a.w;
+    }
+    st.fwd.lo = e.x; st.fwd.hi = e.y; st.rvc.lo = e.z; st.rvc.hi = e.w;
     st.fwd_broken = e.x > e.y;
     st.rvc_broken = e.z > e.w;
     st.size = k;

@@ -32,7 +32,7 @@ __device__ __forceinline__ void prepare_offset(const FmIndexDev& fm, const Stran
     for(uint32_t s = 0; s < kmax;) {
         const uint32_t next_emit = s < 5 ? 5u : s < seedk ? seedk : mink;
         bool jumped = false;
-        if(!WIDE && next_emit <= kmax) {
+        if(next_emit <= kmax) {
             WalkState<P> ts = walk_init<P>();
             const uint32_t tk = table_start<WIDE>(fm, [&](uint32_t t) { return (uint32_t)q[i + t]; }, next_emit, ts);
             if(tk == next_emit) { n_rank += st.n_rank; n_blk += st.n_blk; st = ts; st.n_rank = 0; st.n_blk = 0; s = tk; jumped = true; }
