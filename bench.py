@@ -1,17 +1,28 @@
 #!/usr/bin/env python3
-"""bench.py -- throughput of the PacBio self-correction hot path on N MI355X GPUs of one node.
+"""bench.py -- corrected-read throughput of the PacBio self-correction hot path on N MI355X GPUs of one node.
 
     python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
 
-A "step" is one pass of the device hot path over one resident batch of synthetic reads
-(BASELINE.json configs[1]: 100k x 10 kb reads, 15 % error, over the FM-index of a 90x read set =
-the "1 Gb FM-index").  Reads shard across ranks with the read-only index replicated in every
-GPU's HBM; there is no collective on the data path, only the timing barrier.
+Default workload = BASELINE.json configs[2]: 100k x 10 kb reads (15 % error) per GPU, corrected against the
+FM-index of that same 90x read set (1.05 G symbols per strand = the "1 Gb FM-index"), default flow of
+`stride pbcorrect -c 90 -g 5` (seeds -> seed-to-seed FM-extension -> DP/MSA fallback -> stitching), everything on
+the device, corrected strings and counters downloaded to the host inside the timed region.
 
-One JSON line on stdout (rank 0).  `roofline` prices the dominant kernel (the Occ-rank / k-mer
-grid kernel) by ALGORITHMIC bytes = rank-block loads x 64 B over its HIP-event duration;
-`cpu_baseline` is the CPU oracle (a port of the reference algorithm) timed on this host on a
-bounded sample of the same reads.
+A "step" is one pass of that whole per-read path over one resident sub-batch of `--reads-per-step` reads (the
+rank's reads are cut into sub-batches that stay in HBM; step i processes sub-batch i mod n).  `value` = input
+bases of the timed steps / wall time (max over ranks), summed over ranks.  Reads shard across ranks, the read-only
+index is replicated in every GPU's HBM; there is no collective on the data path, only
+the timing barrier.
+
+One JSON line on stdout (rank 0):
+  roofline      the graded Occ-rank kernel (kmer_grid_kernel) of the same run: algorithmic bytes (rank blocks +
+                k-mer table lines, 64 B each, counted on the device) / its HIP-event time on the ctx stream
+  roofline_extra  the same pricing for correct_reads_kernel (the FM-extension kernel, where the metric lives)
+  cpu_baseline  the CPU oracle (port of the reference algorithm) on all host cores, one thread per core over
+                disjoint reads of the first sub-batch, bounded to about --cpu-seconds
+  parity_sample the oracle's corrected strings and integer counters for those sampled reads compared with what
+                the GPU produced for the same reads in the timed run; a mismatch makes the process exit 3
+`--stage seeds` times configs[1] (Occ-rank + LongReadProbe kernels only) and says so in `metric`.
 """
 from __future__ import annotations
 
@@ -19,6 +30,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 from pathlib import Path
 
@@ -30,30 +42,44 @@ sys.path.insert(0, str(REPO))
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 BLOCK_BYTES = 64
 
+T0 = time.time()
+
 
 def log(msg: str):
     print(f"[bench +{time.time() - T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
-T0 = time.time()
+STAGE_INFO = {
+    "seeds": dict(config=1, metric="seed-stage Mbases/s (whole node; Occ-rank + LongReadProbe kernels only, BASELINE configs[1])",
+                  stages=["LongReadProbe k-mer feature grid (Occ-rank kernel)",
+                          "getSeqAttribute + searchSeedsWithHybridKmers + estimateBestKmerSize + removeHitchhikingSeeds"]),
+    "correct-nodp": dict(config=2, metric="corrected Mbases/s (whole node), --nodp flow",
+                         stages=["seed stage", "seed-to-seed FM-extension chain + stitching (correct_reads_kernel)",
+                                 "download of corrected strings + counters"]),
+    "correct": dict(config=2, metric="corrected Mbases/s (whole node)",
+                    stages=["seed stage", "seed-to-seed FM-extension chain + stitching (correct_reads_kernel)",
+                            "DP/MSA fallback rounds (LF-walk retrieval, extendMatch, multiple alignment + consensus)",
+                            "download of corrected strings + counters"]),
+}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--genome-mb", type=float, default=11.1, help="synthetic genome size; 11.1 Mb x 90x = 100k x 10 kb reads")
     ap.add_argument("--reads", type=int, default=100_000, help="reads per GPU (= index reads on rank 0)")
     ap.add_argument("--read-len", type=int, default=10_000)
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 disables)")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="correct stages only: split the rank's reads over this many contexts on the same GPU, run concurrently "
-                         "(one host thread each) -- the tail of one sub-batch's DP rounds overlaps the other's extension")
-    ap.add_argument("--stage", choices=["seeds", "correct-nodp", "correct"], default="seeds",
-                    help="seeds: BASELINE configs[1] (Occ-rank + LongReadProbe kernels, the default and the graded line); "
-                         "correct-nodp / correct: configs[2], the whole per-read path on the device without / with the DP fallback")
+    ap.add_argument("--reads-per-step", type=int, default=0,
+                    help="reads of one step's resident sub-batch (0 = stage default: all reads for `seeds`, 25000 otherwise)")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 disables it and parity_sample)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="oracle threads of the cpu_baseline leg (0 = all host cores of this process)")
+    ap.add_argument("--stage", choices=list(STAGE_INFO), default="correct",
+                    help="correct (default): BASELINE configs[2], the whole per-read path with the DP fallback; correct-nodp: the "
+                         "same with --nodp; seeds: configs[1], Occ-rank + LongReadProbe kernels only")
     args = ap.parse_args()
+    sinfo = STAGE_INFO[args.stage]
 
     import torch
     import torch.distributed as dist
@@ -93,12 +119,14 @@ def main():
     log(f"index read set: {int(idx_off[-1]) / 1e6:.1f} Mbases, {n_sym / 1e9:.3f} G symbols per strand; building BWTs on the GPU")
     t = time.time()
     units = [api.build_bwt(idx_bases, idx_off, rev, local_rank) for rev in (False, True)]
-    log(f"BWT + rBWT built in {time.time() - t:.1f}s ({units[0].size / 1e6:.0f} M / {units[1].size / 1e6:.0f} M RL units)")
+    build_s = time.time() - t
+    log(f"BWT + rBWT built in {build_s:.1f}s ({units[0].size / 1e6:.0f} M / {units[1].size / 1e6:.0f} M RL units)")
     t = time.time()
     index = api.index_from_units(units[0], units[1], n_reads, n_sym)
     index.upload(local_rank)
     info = index.info()
-    log(f"rank-block image built + uploaded in {time.time() - t:.1f}s: {info.device_bytes / 1e9:.2f} GB in HBM, "
+    upload_s = time.time() - t
+    log(f"rank-block image + k-mer tables built and uploaded in {upload_s:.1f}s: {info.device_bytes / 1e9:.2f} GB of rank blocks in HBM, "
         f"{info.block_symbols} symbols per {info.block_bytes}-byte block")
     params = api.params_default(5, 90)          # -g 5 -c 90: k = 17, pool {5,9,15,17,19}
     params.no_dp = 1 if args.stage == "correct-nodp" else 0
@@ -109,80 +137,93 @@ def main():
     else:
         bases, off = api.synth_reads(0x5EED0002, genome, n_reads, args.read_len,
                                      first_read=lrdist.weak_shard_first_read(rank, n_reads))
-    n_streams = max(1, args.streams) if args.stage != "seeds" else 1
-    ctxs = [ctx] + [index.ctx(params, local_rank) for _ in range(n_streams - 1)]
-    cuts = [len(off) - 1] if n_streams == 1 else [((len(off) - 1) * (i + 1)) // n_streams for i in range(n_streams)]
-    batches, lo = [], 0
-    for c, hi in zip(ctxs, cuts):
+    per_step = args.reads_per_step or (n_reads if args.stage == "seeds" else 25_000)
+    per_step = max(1, min(per_step, n_reads))
+    cuts = list(range(0, n_reads, per_step)) + [n_reads]
+    if len(cuts) > 2 and cuts[-1] - cuts[-2] < per_step // 2:      # fold a short last sub-batch into the one before it
+        del cuts[-2]
+    batches, batch_bases = [], []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
         sub_off = (off[lo: hi + 1] - off[lo]).astype(np.uint64)
-        batches.append(c.batch(bases[int(off[lo]): int(off[hi])], sub_off))
-        lo = hi
-    batch = batches[0]
-    my_bases = int(off[-1])
-    log(f"batch resident in HBM: {my_bases / 1e6:.1f} Mbases in {n_streams} sub-batch(es)")
+        batches.append(ctx.batch(bases[int(off[lo]): int(off[hi])], sub_off))
+        batch_bases.append(int(off[hi]) - int(off[lo]))
+    log(f"{len(batches)} sub-batch(es) resident in HBM: {[b.n_reads for b in batches]} reads, {int(off[-1]) / 1e6:.1f} Mbases in all")
 
-    fm_walks = [0, 0, 0]
+    totals = {"walks": 0, "fm": 0, "dp": 0, "corrected_reads": 0, "corrected_bases": 0}
+    kept = {}            # results of sub-batch 0 from its latest pass (parity_sample compares them with the oracle)
 
-    def run_one(b, acc):
+    def step(i, timed):
+        j = i % len(batches)
+        b = batches[j]
         b.find_seeds()          # k-mer grid (Occ-rank kernel) + getSeqAttribute + greedy seed scan, all on the device
         if args.stage != "seeds":
-            res, _, _ = b.correct()          # chain of seed-to-seed FM-extensions (+ DP/MSA rounds) and stitching, on the device
-            acc.append((sum(r.total_walk_num for r in res), sum(r.fm_num for r in res), sum(r.dp_num for r in res)))
+            res, poff, out = b.correct()      # FM-extension chain (+ DP/MSA rounds) and stitching on the device; results on the host
+            if timed:
+                totals["walks"] += sum(r.total_walk_num for r in res)
+                totals["fm"] += sum(r.fm_num for r in res)
+                totals["dp"] += sum(r.dp_num for r in res)
+                totals["corrected_reads"] += sum(1 for r in res if r.merge)
+                totals["corrected_bases"] += int(out.size)
+            if j == 0:
+                kept["res"], kept["poff"], kept["out"] = res, poff.copy(), out.copy()
+        return batch_bases[j]
 
-    def step():
-        acc = []
-        if len(batches) == 1:
-            run_one(batches[0], acc)
-        else:
-            import threading
-            ts = [threading.Thread(target=run_one, args=(b, acc)) for b in batches]
-            for t in ts: t.start()
-            for t in ts: t.join()
-        for j in range(3):
-            fm_walks[j] = sum(a[j] for a in acc)
-
-    for _ in range(args.warmup):
-        step()
-    for c in ctxs:
-        c.stats_reset()
+    for i in range(args.warmup):
+        step(i, False)
+    ctx.stats_reset()
 
     def fence():
-        for c in ctxs:
-            c.sync()
+        ctx.sync()
         torch.cuda.synchronize()
         lrdist.barrier()
         torch.cuda.synchronize()
 
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    my_bases = 0
+    for i in range(args.steps):
+        my_bases += step(args.warmup + i, True)
     fence()
     elapsed = time.perf_counter() - t0
 
     # max over ranks of the elapsed time; sum over ranks of the bases processed
     elapsed_max, total_bases = lrdist.combine(elapsed, float(my_bases), device="cpu" if one_device else "cuda")
 
-    st = ctx.stats(K_GRID)
-    st_seeds = ctx.stats(K_SEEDS)
-    kernel_ms = st.total_ms / max(st.launches, 1)
-    # algorithmic 64-byte lines per launch: rank blocks + k-mer-table entries (one line each)
-    lines_per_launch = (st.block_loads + st.table_loads) / max(st.launches, 1)
-    achieved = lines_per_launch * BLOCK_BYTES / (kernel_ms * 1e-3) / 1e9
-
-    # HBM-side traffic of the same kernel on the same workload comes from the committed rocprofv3 --pmc
-    # pass (it cannot be sampled from inside the process); null for any other workload.
-    traffic, traffic_src = None, None
-    pmc = REPO / "profiles" / "r01_pmc" / "traffic_v10.json"
-    if pmc.exists() and n_reads == 100_000 and abs(args.genome_mb - 11.1) < 1e-9 and args.read_len == 10_000:
-        pj = json.loads(pmc.read_text())
-        traffic, traffic_src = pj["traffic_bytes_per_launch"] / 1e9, pj["source"]
+    def roofline_of(which, name):
+        st = ctx.stats(which)
+        launches = max(st.launches, 1)
+        ms = st.total_ms / launches
+        lines = (st.block_loads + st.table_loads) / launches
+        ach = lines * BLOCK_BYTES / max(ms * 1e-3, 1e-12) / 1e9
+        return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": None, "algorithmic_gb_per_launch": lines * BLOCK_BYTES / 1e9, "kernel_ms": ms, "launches": int(st.launches),
+                "block_loads_per_launch": st.block_loads / launches, "table_loads_per_launch": st.table_loads / launches,
+                "rank_queries_per_launch": st.rank_queries / launches}
 
     result = None
+    rc = 0
     if rank == 0:
-        value = total_bases * args.steps / elapsed_max / 1e6
+        roof = roofline_of(K_GRID, "kmer_grid_kernel")
+        # HBM-side traffic of the same kernel on the same launch shape comes from the committed rocprofv3 --pmc passes (counters
+        # cannot be sampled from inside the process); null for any other workload
+        pmc = REPO / "profiles" / "r02_pmc" / "traffic.json"
+        if pmc.exists():
+            pj = json.loads(pmc.read_text())
+            if pj.get("reads_per_launch") == batches[0].n_reads and pj.get("index_reads") == n_reads and pj.get("read_len") == args.read_len:
+                roof["traffic"] = pj["traffic_bytes_per_launch"] / 1e9
+                roof["traffic_unit"] = "GB per launch (separate rocprofv3 --pmc passes, corrected as MI355X_MICROARCH.md prescribes)"
+                roof["traffic_source"] = pj["source"]
+        value = total_bases / elapsed_max / 1e6
+        st_seeds = ctx.stats(K_SEEDS)
+        stage_ms = {"kmer_grid": ctx.stats(K_GRID).total_ms / args.steps, "seed_scan_group": st_seeds.total_ms / args.steps}
+        if args.stage != "seeds":
+            stage_ms.update({"fm_extend_and_stitch": ctx.stats(K_EXTEND).total_ms / args.steps,
+                             "fm_extend_launches_per_step": ctx.stats(K_EXTEND).launches / args.steps,
+                             "dp_retrieve_lf_walks": ctx.stats(K_LF).total_ms / args.steps,
+                             "dp_extend_match": ctx.stats(K_DP).total_ms / args.steps,
+                             "dp_msa_consensus": ctx.stats(K_MSA).total_ms / args.steps})
         result = {
-            "metric": "corrected Mbases/s (whole node)",
+            "metric": sinfo["metric"],
             "value": value,
             "unit": "Mbases/s",
             "n_gpus": world,
@@ -195,94 +236,158 @@ def main():
             "dtype": "int64",
             "data": "synthetic",
             "config": {
-                "workload": (f"BASELINE configs[{1 if args.stage == 'seeds' else 2}]: {n_reads} x {args.read_len / 1000:g} kb reads/GPU (15% err: 4.5% del, 1.5% sub, 9% ins) "
-                             f"over the FM-index of the {n_reads}-read 90x set of a {args.genome_mb:g} Mb genome "
-                             f"({n_sym / 1e9:.2f} G symbols/strand), -c 90 -g 5"),
-                "stages_timed": ["LongReadProbe k-mer feature grid (Occ-rank kernel)",
-                                 "getSeqAttribute + searchSeedsWithHybridKmers + estimateBestKmerSize + removeHitchhikingSeeds"],
-                "stage_ms": {"kmer_grid": kernel_ms, "seed_scan_group": st_seeds.total_ms / max(st_seeds.launches, 1),
-                             **({} if args.stage == "seeds" else {
-                                 "fm_extend_and_stitch": sum(c.stats(K_EXTEND).total_ms for c in ctxs) / args.steps,
-                                 "dp_retrieve_lf_walks": sum(c.stats(K_LF).total_ms for c in ctxs) / args.steps,
-                                 "dp_extend_match": sum(c.stats(K_DP).total_ms for c in ctxs) / args.steps,
-                                 "dp_msa_consensus": sum(c.stats(K_MSA).total_ms for c in ctxs) / args.steps,
-                                 "concurrent_contexts": n_streams})},
-                **({} if args.stage == "seeds" else {"stage": args.stage, "walks_per_step": fm_walks[0], "fm_walks": fm_walks[1], "dp_walks": fm_walks[2]}),
+                "workload": (f"BASELINE configs[{sinfo['config']}]: {n_reads} x {args.read_len / 1000:g} kb reads/GPU (15% err: 4.5% del, 1.5% sub, "
+                             f"9% ins) over the FM-index of the {n_reads}-read 90x set of a {args.genome_mb:g} Mb genome "
+                             f"({n_sym / 1e9:.2f} G symbols/strand), -c 90 -g 5{' --nodp' if args.stage == 'correct-nodp' else ''}; "
+                             f"one step = one resident sub-batch of {batches[0].n_reads} reads ({batch_bases[0] / 1e6:.0f} Mbases) through "
+                             f"{'the seed stage' if args.stage == 'seeds' else 'the whole per-read path, results downloaded'}"),
+                "stage": args.stage,
+                "stages_timed": sinfo["stages"],
+                "stage_ms_per_step": stage_ms,
+                "reads_per_step": batches[0].n_reads,
+                "sub_batches": len(batches),
+                **({} if args.stage == "seeds" else {
+                    "walks": totals["walks"], "fm_walks": totals["fm"], "dp_walks": totals["dp"],
+                    "corrected_reads": totals["corrected_reads"], "corrected_bases_out": totals["corrected_bases"]}),
                 "index_hbm_gb": info.device_bytes / 1e9,
+                "index_build_s": build_s, "index_upload_and_tables_s": upload_s,
                 "reads_per_gpu": n_reads,
                 "parallelism": f"reads sharded x{world}, index replicated, no data-path collective",
             },
-            "roofline": {
-                "kernel": "kmer_grid_kernel",
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "traffic_unit": "GB per launch (FETCH_SIZE x 1024, separate --pmc pass)",
-                "traffic_source": traffic_src,
-                "algorithmic_gb_per_launch": lines_per_launch * BLOCK_BYTES / 1e9,
-                "table_loads_per_launch": st.table_loads / max(st.launches, 1),
-                "kernel_ms": kernel_ms,
-                "block_loads_per_launch": st.block_loads / max(st.launches, 1),
-                "rank_queries_per_launch": st.rank_queries / max(st.launches, 1),
-            },
+            "roofline": roof,
         }
+        if args.stage != "seeds":
+            result["roofline_extra"] = [roofline_of(K_EXTEND, "correct_reads_kernel")]
         if world == 1 and args.cpu_seconds > 0:
-            result["cpu_baseline"] = cpu_baseline(units, n_reads, n_sym, params, bases, off, args.cpu_seconds, args.stage)
+            cb, ps = cpu_baseline(units, n_reads, n_sym, params, bases, off, cuts[1], args, kept, batches[0])
+            result["cpu_baseline"] = cb
+            if ps is not None:
+                result["parity_sample"] = ps
+                if not ps["identical"]:
+                    rc = 3
         print(json.dumps(result), flush=True)
 
     for b in batches:
         b.close()
-    for c in ctxs:
-        c.close()
+    ctx.close()
     index.close()
     if world > 1:
         dist.destroy_process_group()
+    if rc:
+        log("parity_sample: the GPU results differ from the CPU oracle's for the sampled reads")
+        sys.exit(rc)
 
 
-def cpu_baseline(units, n_reads, n_sym, params, bases, off, budget_s, stage="seeds"):
-    """The CPU oracle (port of the reference's path for the same stages) on a bounded sample of the same reads."""
+def host_cores() -> int:
+    """Cores this process may really use: the affinity mask capped by the cgroup CPU quota (a GPU box hands a one-GPU job a
+    16-core share of a 256-core host; 256 oracle threads on 16 cores would run 16x over the time budget)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    cap = int(os.environ.get("LRSC_BENCH_MAX_CPU_THREADS", "32"))
+    return max(1, min(n, cap))
+
+
+def cpu_baseline(units, n_reads, n_sym, params, bases, off, batch0_reads, args, kept, batch0):
+    """The CPU oracle (port of the reference's path for the same stages) on a bounded sample of sub-batch 0, one thread per
+    host core over disjoint reads (ctypes releases the GIL; the index is shared read-only).  For the correct stages the oracle's
+    strings and counters of the sampled reads are compared with the GPU's (parity_sample)."""
     from oracle import oracle_py
 
-    log("cpu_baseline: loading the index into the CPU oracle (RLBWT markers)")
+    stage = args.stage
+    threads = args.cpu_threads or host_cores()
+    log(f"cpu_baseline: loading the index into the CPU oracle (RLBWT markers); {threads} thread(s)")
     orc = oracle_py.Oracle()
     ob = orc.bwt_from_units(units[0], n_reads, n_sym)
     orb = orc.bwt_from_units(units[1], n_reads, n_sym)
-    ks = np.array([5, 9, 15, 17, 19], dtype=np.uint8)
-    if stage != "seeds":
-        t = time.perf_counter()
-        orc.correct_reads(ob, orb, params, bases[: int(off[2])], off[:3].copy()).close()
-        per_read = (time.perf_counter() - t) / 2
-        n = int(max(2, min(len(off) - 1, budget_s / max(per_read, 1e-6))))
-        log(f"cpu_baseline: {per_read * 1e3:.0f} ms/read -> sampling {n} reads")
-        t = time.perf_counter()
-        run = orc.correct_reads(ob, orb, params, bases[: int(off[n])], off[: n + 1].copy())
-        dt = time.perf_counter() - t
-        walks = int(run.counters[:, 3].sum())
+
+    def run_chunk(lo, hi):
+        sub_off = (off[lo: hi + 1] - off[lo]).astype(np.uint64)
+        sub = bases[int(off[lo]): int(off[hi])]
+        if stage == "seeds":
+            return orc.find_seeds(ob, orb, params, sub, sub_off)
+        run = orc.correct_reads(ob, orb, params, sub, sub_off)
+        got = (run.correct_fa, run.counters.copy())
         run.close()
-        return {"value": int(off[n]) / dt / 1e6, "unit": "Mbases/s", "cores": 1, "kind": "port",
-                "sample": f"first {n} reads ({int(off[n]) / 1e6:.2f} Mbases, {walks} walks) of the same batch, whole per-read path "
-                          f"(PacBioSelfCorrectionProcess::process, no_dp={params.no_dp}), oracle/ restatement, 1 thread, {dt:.1f}s"}
-    # calibrate on 2 reads, then size the sample to the budget
+        return got
+
+    # calibrate on 2 reads (one thread), then size the sample to the budget
     t = time.perf_counter()
-    orc.find_seeds(ob, orb, params, bases[: int(off[2])], off[:3].copy())
+    run_chunk(0, 2)
     per_read = (time.perf_counter() - t) / 2
-    n = int(max(2, min(len(off) - 1, budget_s / max(per_read, 1e-6))))
-    log(f"cpu_baseline: {per_read * 1e3:.0f} ms/read -> sampling {n} reads")
+    n = int(max(threads, min(batch0_reads, args.cpu_seconds / max(per_read, 1e-6) * threads)))
+    n -= n % threads
+    log(f"cpu_baseline: {per_read * 1e3:.0f} ms/read/thread -> sampling {n} reads over {threads} threads")
+    bounds = [n * i // threads for i in range(threads + 1)]
+    outs = [None] * threads
+
+    def worker(i):
+        outs[i] = run_chunk(bounds[i], bounds[i + 1])
+
     t = time.perf_counter()
-    count, _, _ = orc.find_seeds(ob, orb, params, bases[: int(off[n])], off[: n + 1].copy())
+    ths = [threading.Thread(target=worker, args=(i,)) for i in range(threads)]
+    for th in ths: th.start()
+    for th in ths:
+        while th.is_alive():
+            th.join(timeout=30.0)
+            if th.is_alive():
+                log(f"cpu_baseline: {sum(o is not None for o in outs)} of {threads} oracle threads done")
     dt = time.perf_counter() - t
-    return {
-        "value": int(off[n]) / dt / 1e6,
-        "unit": "Mbases/s",
-        "cores": 1,
-        "kind": "port",
-        "sample": f"first {n} reads ({int(off[n]) / 1e6:.2f} Mbases, {int(count.sum())} seeds) of the same batch, same stages "
-                  f"(LongReadProbe::searchSeedsWithHybridKmers), oracle/ restatement over the reference's RLBWT layout, "
-                  f"1 thread, {dt:.1f}s",
-    }
+    sample_bases = int(off[n])
+    cb = {"value": sample_bases / dt / 1e6, "unit": "Mbases/s", "cores": threads, "kind": "port",
+          "per_core": sample_bases / dt / 1e6 / threads,
+          "sample": f"first {n} reads ({sample_bases / 1e6:.2f} Mbases) of sub-batch 0, "
+                    f"{'seed stage (LongReadProbe::searchSeedsWithHybridKmers)' if stage == 'seeds' else 'whole per-read path (PacBioSelfCorrectionProcess::process, no_dp=%d)' % params.no_dp}, "
+                    f"oracle/ restatement over the reference's RLBWT layout (g++ -O3, no -march), {threads} threads x {n // threads} reads, {dt:.1f}s"}
+    if stage == "seeds":
+        # compare the seeds of the sampled reads with the GPU's
+        count_g, seeds_g, _ = batch0.seeds(want_attribute=False)
+        ok, first_bad, pos = True, None, 0
+        starts = np.concatenate([[0], np.cumsum(count_g.astype(np.int64))])
+        for i in range(threads):
+            count_o, seeds_o, _ = outs[i]
+            lo, hi = bounds[i], bounds[i + 1]
+            g = seeds_g[int(starts[lo]): int(starts[hi])]
+            g_arr = np.stack([g[f] for f in g.dtype.names], axis=1) if g.size else np.zeros((0, 8), dtype=np.int32)
+            if not (np.array_equal(count_o, count_g[lo:hi]) and np.array_equal(np.asarray(seeds_o).reshape(-1, 8), g_arr)):
+                ok, first_bad = False, lo
+                break
+        return cb, {"reads": n, "identical": ok, "compared": "seed counts + all 8 fields of every seed", "first_mismatch_chunk_at_read": first_bad}
+    if "res" not in kept:
+        return cb, None
+    res, poff, out = kept["res"], kept["poff"], kept["out"].tobytes()
+    ok, first_bad = True, None
+    fields = ("total_reads_len", "corrected_len", "total_seed_num", "total_walk_num", "high_error_num", "exceed_depth_num",
+              "exceed_leave_num", "fm_num", "dp_num", "seed_dis")
+    for i in range(threads):
+        fa_o, ctr_o = outs[i]
+        lo, hi = bounds[i], bounds[i + 1]
+        parts = []
+        for r in range(lo, hi):
+            R = res[r]
+            if R.merge:
+                for pj in range(R.piece_first, R.piece_first + R.n_pieces):
+                    parts.append(f">r{r - lo}\n{out[int(poff[pj]): int(poff[pj + 1])].decode()}\n")
+        ctr_g = np.array([[getattr(res[r], f) for f in fields] + [1 if res[r].merge else 0] for r in range(lo, hi)], dtype=np.int64)
+        if "".join(parts) != fa_o or not np.array_equal(ctr_g, ctr_o):
+            ok, first_bad = False, lo
+            break
+    return cb, {"reads": n, "identical": ok, "compared": "correct.fa records + the 10 integer counters + merge flag of every sampled read",
+                "first_mismatch_chunk_at_read": first_bad}
 
 
 if __name__ == "__main__":

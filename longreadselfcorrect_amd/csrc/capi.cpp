@@ -23,6 +23,7 @@
 #include "kernels.h"
 #include "extend.h"
 #include "correct_dev.h"
+#include "correct_layout.h"
 #include "dp_dev.h"
 #include "introsort_emul.h"
 
@@ -815,17 +816,7 @@ extern "C" int lrsc_batch_kmer_grid(lrsc_ctx* ctx, lrsc_batch* b)
     int st = batch_setup_rows(ctx, b);
     if(st != LRSC_OK) return st;
     const GridArgs a = batch_grid_args(b);
-    // One lane per position is the default.  LRSC_GRID_MODE=quad selects the quad-cooperative kernel
-    // (grid_quad.hip), kept for experiments: on config[1] it is ~4x slower because it quarters the
-    // lines in flight per wavefront and this kernel is latency/MLP-bound (profiles/).
-    const char* mode = std::getenv("LRSC_GRID_MODE");
-    const bool quad = !ctx->fm.wide && mode && std::strcmp(mode, "quad") == 0;
-    const bool coop = !ctx->fm.wide && mode && std::strcmp(mode, "coop") == 0;
-    st = timed_launch(ctx, LRSC_K_GRID, [&]() {
-        return quad ? launch_kmer_grid_quad(ctx->fm, a, ctx->d_ctr, ctx->stream)
-             : coop ? launch_kmer_grid_coop(ctx->fm, a, ctx->d_ctr, ctx->stream)
-                    : launch_kmer_grid(ctx->fm, a, ctx->d_ctr, ctx->stream);
-    });
+    st = timed_launch(ctx, LRSC_K_GRID, [&]() { return launch_kmer_grid(ctx->fm, a, ctx->d_ctr, ctx->stream); });
     if(st == LRSC_OK) b->grid_done = true;
     return st;
 }
@@ -1392,6 +1383,10 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
         a.occupancy = 4;
         if(const char* e = std::getenv("LRSC_CORRECT_OCC")) a.occupancy = std::atoi(e) >= 4 ? 4u : 2u;   // 8 (64 VGPRs) spills too much: 38 s vs 21 s at 100k reads
+        {
+            const char* ke = std::getenv("LRSC_CORRECT_KERNEL");
+            if(!(ke && std::strcmp(ke, "lane") == 0)) a.occupancy = 2;     // the state-machine kernel is built for 2 wavefronts per SIMD
+        }
         const uint32_t resident = (uint32_t)cus * 4u * a.occupancy;
         a.reads_per_wave = 4;
         while(a.reads_per_wave < 64 && (n + a.reads_per_wave - 1) / a.reads_per_wave > resident) a.reads_per_wave *= 2;
@@ -1430,40 +1425,11 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
         const uint32_t ns = seed_count[r];
         w.out_off = out_total; w.piece_off = piece_total; w.ws_off = ws_total;
         if(ns < 2) continue;                                          // nothing to correct: the read is discarded
-        // every walk appends at most maxLength + 1 + |target| - initk characters, walks <= seeds, gaps sum to <= |read|
-        // (a DP consensus can be longer than its query by the insertion columns it keeps: budget 2x the raw segment)
-        const uint64_t cap = rlen + (uint64_t)((p.no_dp ? 1.2 : 2.0) * (double)rlen) + (uint64_t)ns * (2 * kMaxInitK + 16 + (p.no_dp ? 0 : 128)) + 64;
-        if(cap >= (1ull << 32)) return fail(LRSC_ERR_UNSUPPORTED, "read too long");
-        w.out_cap = (uint32_t)cap;
-        w.piece_cap = p.split ? ns : 1;
-        out_total += (cap + 15) & ~15ull;
+        const char* lerr = nullptr;
+        const size_t o = layout_read_work(w, rlen, ns, plan[r], p.no_dp != 0, p.split != 0, (uint32_t)p.idmer_len, psz, lbytes, &lerr);
+        if(lerr) return fail(LRSC_ERR_UNSUPPORTED, lerr);
+        out_total += ((uint64_t)w.out_cap + 15) & ~15ull;
         piece_total += w.piece_cap;
-        w.lq_max = plan[r].lq_max;
-        if(w.lq_max >= 65535) return fail(LRSC_ERR_UNSUPPORTED, "walk: query longer than 65534 bases");
-        const double maxLength = (1.2 * ((double)plan[r].gap_max + 10)) + (double)(2 * (uint64_t)kMaxInitK);
-        w.pathw = (uint32_t)(((uint64_t)maxLength + 4 + 15) / 16 + 1);
-        const uint32_t lq = std::max<uint32_t>(w.lq_max, 16);
-        const uint32_t n9 = lq - (uint32_t)p.idmer_len + 1, n5 = lq - 5 + 1;
-        const uint32_t nT = lq;                                       // >= |target| - minOverlap + 1
-        size_t o = 0;
-        w.o_item9f = (uint32_t)o; o += (size_t)n9 * sizeof(SortItem);
-        w.o_item9r = (uint32_t)o; o += (size_t)n9 * sizeof(SortItem);
-        w.o_term = (uint32_t)o;   o = align_up(o + (size_t)nT * 4 * psz, 16);
-        w.o_leaves = (uint32_t)o; o = align_up(o + (size_t)(32 + kMaxChildren) * lbytes, 16);
-        w.o_rings = (uint32_t)o;  o += (size_t)32 * 100 * sizeof(double);
-        w.o_results = (uint32_t)o; o += (size_t)kMaxResults * sizeof(WalkResultRec);
-        w.o_paths = (uint32_t)o;  o += (size_t)(32 + kMaxResults) * w.pathw * 4;
-        w.o_best = (uint32_t)o;   o += (size_t)w.pathw * 4;
-        w.o_next9f = (uint32_t)o; o += (size_t)n9 * 2;
-        w.o_next9r = (uint32_t)o; o += (size_t)n9 * 2;
-        w.o_head9 = (uint32_t)o;  o += 512 * 2;
-        w.o_head5 = (uint32_t)o;  o += 1024 * 2;
-        w.o_next5 = (uint32_t)o;  o += (size_t)n5 * 2;
-        w.o_flags5 = (uint32_t)o; o += n5;
-        w.o_query = (uint32_t)o;  o += lq;
-        w.o_dpq = (uint32_t)o;    o += lq;
-        o = align_up(o, 64);
-        if(o >= (1ull << 32)) return fail(LRSC_ERR_UNSUPPORTED, "read workspace too large");
         ws_total += o;
     }
     // launch order: long reads first, similar lengths share a wavefront
@@ -1492,6 +1458,28 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
         x.queue_waves = std::max<uint32_t>(1, (x.n_reads + x.reads_per_wave * queue_rpl - 1) / (x.reads_per_wave * queue_rpl));
         return hipMemsetAsync(d_queue.p, 0, sizeof(uint32_t), ctx->stream);
     };
+    // LRSC_CORRECT_KERNEL=lane selects round 1's lane-per-read kernel with nested control flow (kept for A/B runs);
+    // the default is the wavefront-convergent state machine (correct_sm.hip), which reads its arguments from device memory:
+    // a ring of argument slots, one per launch
+    const char* kern_env = std::getenv("LRSC_CORRECT_KERNEL");
+    const bool use_sm = !(kern_env && std::strcmp(kern_env, "lane") == 0);
+    constexpr uint32_t kArgSlots = 16;
+    DevBuf<CorrectArgs> d_args;
+    DevBuf<FmIndexDev> d_fm;
+    uint32_t arg_slot = 0;
+    if(use_sm) {
+        HIP_TRY(d_args.reserve(kArgSlots));
+        HIP_TRY(d_fm.reserve(1));
+        HIP_TRY(hipMemcpyAsync(d_fm.p, &ctx->fm, sizeof(FmIndexDev), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    auto launch_correct = [&](const CorrectArgs& x, hipStream_t s) -> hipError_t {
+        if(!use_sm) return launch_correct_reads(ctx->fm, x, s);
+        CorrectArgs* slot = d_args.p + (arg_slot++ % kArgSlots);
+        hipError_t e1 = hipMemcpyAsync(slot, &x, sizeof(CorrectArgs), hipMemcpyHostToDevice, s);
+        if(e1 != hipSuccess) return e1;
+        return launch_correct_sm(d_fm.p, slot, x, ctx->fm.wide != 0, s);
+    };
     a.profile = std::getenv("LRSC_CORRECT_PROFILE") ? 1u : 0u;
     a.setup_quorum_pct = 40;
     if(const char* e = std::getenv("LRSC_CORRECT_QUORUM")) a.setup_quorum_pct = (uint32_t)std::min(100, std::max(0, std::atoi(e)));
@@ -1500,7 +1488,7 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
     if(const char* e = std::getenv("LRSC_CORRECT_MAX_WALKS")) a.max_walks = (uint32_t)std::max(0, std::atoi(e));
     if(const char* e = std::getenv("LRSC_CORRECT_MAX_STEPS")) a.max_steps = (uint32_t)std::max(1, std::atoi(e));
     HIP_TRY(with_queue(a));
-    int st = timed_launch(ctx, LRSC_K_EXTEND, [&]() { return launch_correct_reads(ctx->fm, a, ctx->stream); });
+    int st = timed_launch(ctx, LRSC_K_EXTEND, [&]() { return launch_correct(a, ctx->stream); });
     if(st != LRSC_OK) return st;
 
     // ---- DP rounds: reads whose FM-extension failed are parked with a correctByMSAlignment request; the DP stage
@@ -1558,7 +1546,7 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
                 by.reads_per_wave = rpw_for(by.n_reads);
                 by.ctr = nullptr;                               // the main stream's launches own the statistics counters
                 HIP_TRY(hipEventRecord(y0, ystream));
-                hipError_t ey = launch_correct_reads(ctx->fm, by, ystream);
+                hipError_t ey = launch_correct(by, ystream);
                 if(ey != hipSuccess) return hip_fail(ey, "correct_reads (yielded)");
                 HIP_TRY(hipEventRecord(y1, ystream));
             }
@@ -1572,7 +1560,7 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
                 b2.reads_per_wave = rpw_for(b2.n_reads);
                 b2.dp_index = d_dp_index.p; b2.dp_reqs = stage.d_reqs.p; b2.dp_msa = stage.d_msa.p; b2.dp_cons = stage.d_cons.p;
                 HIP_TRY(with_queue(b2));
-                st = timed_launch(ctx, LRSC_K_EXTEND, [&]() { return launch_correct_reads(ctx->fm, b2, ctx->stream); });
+                st = timed_launch(ctx, LRSC_K_EXTEND, [&]() { return launch_correct(b2, ctx->stream); });
                 if(st != LRSC_OK) return st;
             }
             if(!yielded.empty()) {

@@ -82,6 +82,8 @@ struct CorrectArgs {
 
 hipError_t launch_correct_plan(const CorrectArgs& a, hipStream_t stream);
 hipError_t launch_correct_reads(const FmIndexDev& fm, const CorrectArgs& a, hipStream_t stream);
+// the wavefront-convergent state-machine form (correct_sm.hip): d_fm / d_args are device copies of fm / a
+hipError_t launch_correct_sm(const FmIndexDev* d_fm, const CorrectArgs* d_args, const CorrectArgs& a, bool wide, hipStream_t stream);
 // out_codes -> ASCII, packed at dst + dst_off[r]
 hipError_t launch_correct_gather(const CorrectArgs& a, const uint64_t* dst_off, char* dst, hipStream_t stream);
 

@@ -92,10 +92,6 @@ hipError_t launch_bwt_chars(const FmIndexDev& fm, int strand, const uint64_t* id
 hipError_t launch_find_kmers(const FmIndexDev& fm, const uint8_t* kmer_codes, uint32_t k, uint64_t n,
                              lrsc_biinterval* out, DevCounters* ctr, hipStream_t stream);
 hipError_t launch_kmer_grid(const FmIndexDev& fm, const GridArgs& a, DevCounters* ctr, hipStream_t stream);
-// compact-output grid with quad-cooperative block loads (Block32 indexes only; grid_quad.hip)
-hipError_t launch_kmer_grid_quad(const FmIndexDev& fm, const GridArgs& a, DevCounters* ctr, hipStream_t stream);
-// compact-output grid, every lane its own search, rank blocks fetched four-lanes-per-line through LDS (grid_coop.hip)
-hipError_t launch_kmer_grid_coop(const FmIndexDev& fm, const GridArgs& a, DevCounters* ctr, hipStream_t stream);
 // ASCII -> 2-bit code per byte; *bad set to 1 if a byte is not one of ACGT
 hipError_t launch_encode(const char* ascii, uint8_t* codes, uint64_t n, int* bad, hipStream_t stream);
 hipError_t launch_chunk_table(const uint64_t* read_off, uint32_t n_reads, uint64_t total_bases,

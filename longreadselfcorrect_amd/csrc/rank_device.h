@@ -19,14 +19,14 @@ template <> struct Lay<false> {
     static constexpr uint32_t kWords = Block32::kWords;
     static constexpr uint32_t kRow = 8;                    // mask-table row stride (u32)
     struct Regs { uint4 q[4]; };                           // q0 = counts, q[j] = {lo[2j-2], lo[2j-1], hi[2j-2], hi[2j-1]}
-    static __device__ __forceinline__ void load(const void* blocks, uint64_t b, Regs& r)
+    static __host__ __device__ __forceinline__ void load(const void* blocks, uint64_t b, Regs& r)
     {
         const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const Block32*>(blocks) + b);
         r.q[0] = p[0]; r.q[1] = p[1]; r.q[2] = p[2]; r.q[3] = p[3];
     }
-    static __device__ __forceinline__ bool flagged(const Regs& r) { return (r.q[0].x & kFlag32) != 0; }
+    static __host__ __device__ __forceinline__ bool flagged(const Regs& r) { return (r.q[0].x & kFlag32) != 0; }
     // symbols equal to `code` among the first `off` symbols of the block + the block's base count
-    static __device__ __forceinline__ uint64_t count(const Regs& r, uint32_t code, const uint32_t* __restrict__ mrow)
+    static __host__ __device__ __forceinline__ uint64_t count(const Regs& r, uint32_t code, const uint32_t* __restrict__ mrow)
     {
         const uint32_t base = code == 0 ? (r.q[0].x & ~kFlag32) : code == 1 ? r.q[0].y : code == 2 ? r.q[0].z : r.q[0].w;
         const uint32_t L = (code & 1u) ? 0u : 0xFFFFFFFFu;
@@ -43,7 +43,7 @@ template <> struct Lay<false> {
         return c;
     }
     // the same for two prefix lengths of one block
-    static __device__ __forceinline__ void count2(const Regs& r, uint32_t code, const uint32_t* __restrict__ mrow_a,
+    static __host__ __device__ __forceinline__ void count2(const Regs& r, uint32_t code, const uint32_t* __restrict__ mrow_a,
                                                   const uint32_t* __restrict__ mrow_b, uint64_t& ca, uint64_t& cb)
     {
         const uint32_t base = code == 0 ? (r.q[0].x & ~kFlag32) : code == 1 ? r.q[0].y : code == 2 ? r.q[0].z : r.q[0].w;
@@ -64,7 +64,7 @@ template <> struct Lay<false> {
         x += __builtin_popcount(m[5] & a1.y); y += __builtin_popcount(m[5] & b1.y);
         ca = x; cb = y;
     }
-    static __device__ __forceinline__ uint32_t symbol(const Regs& r, uint32_t off)
+    static __host__ __device__ __forceinline__ uint32_t symbol(const Regs& r, uint32_t off)
     {
         const uint32_t lo[6] = {r.q[1].x, r.q[1].y, r.q[2].x, r.q[2].y, r.q[3].x, r.q[3].y};
         const uint32_t hi[6] = {r.q[1].z, r.q[1].w, r.q[2].z, r.q[2].w, r.q[3].z, r.q[3].w};
@@ -81,14 +81,14 @@ template <> struct Lay<true> {
     static constexpr uint32_t kWords = Block64::kWords;
     static constexpr uint32_t kRow = 4;
     struct Regs { uint4 q[4]; };                           // q0,q1 = counts, q2 = lo[4], q3 = hi[4]
-    static __device__ __forceinline__ void load(const void* blocks, uint64_t b, Regs& r)
+    static __host__ __device__ __forceinline__ void load(const void* blocks, uint64_t b, Regs& r)
     {
         const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const Block64*>(blocks) + b);
         r.q[0] = p[0]; r.q[1] = p[1]; r.q[2] = p[2]; r.q[3] = p[3];
     }
-    static __device__ __forceinline__ uint64_t u64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
-    static __device__ __forceinline__ bool flagged(const Regs& r) { return (r.q[0].y & 0x80000000u) != 0; }
-    static __device__ __forceinline__ uint64_t count(const Regs& r, uint32_t code, const uint32_t* __restrict__ mrow)
+    static __host__ __device__ __forceinline__ uint64_t u64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
+    static __host__ __device__ __forceinline__ bool flagged(const Regs& r) { return (r.q[0].y & 0x80000000u) != 0; }
+    static __host__ __device__ __forceinline__ uint64_t count(const Regs& r, uint32_t code, const uint32_t* __restrict__ mrow)
     {
         const uint64_t base = code == 0 ? (u64(r.q[0].x, r.q[0].y) & ~kFlag64) : code == 1 ? u64(r.q[0].z, r.q[0].w)
                             : code == 2 ? u64(r.q[1].x, r.q[1].y) : u64(r.q[1].z, r.q[1].w);
@@ -102,7 +102,7 @@ template <> struct Lay<true> {
         c += __builtin_popcount((r.q[2].w ^ L) & (r.q[3].w ^ H) & m0.w);
         return base + c;
     }
-    static __device__ __forceinline__ void count2(const Regs& r, uint32_t code, const uint32_t* __restrict__ mrow_a,
+    static __host__ __device__ __forceinline__ void count2(const Regs& r, uint32_t code, const uint32_t* __restrict__ mrow_a,
                                                   const uint32_t* __restrict__ mrow_b, uint64_t& ca, uint64_t& cb)
     {
         const uint64_t base = code == 0 ? (u64(r.q[0].x, r.q[0].y) & ~kFlag64) : code == 1 ? u64(r.q[0].z, r.q[0].w)
@@ -120,7 +120,7 @@ template <> struct Lay<true> {
         x += __builtin_popcount(m[3] & a0.w); y += __builtin_popcount(m[3] & b0.w);
         ca = base + x; cb = base + y;
     }
-    static __device__ __forceinline__ uint32_t symbol(const Regs& r, uint32_t off)
+    static __host__ __device__ __forceinline__ uint32_t symbol(const Regs& r, uint32_t off)
     {
         const uint32_t lo[4] = {r.q[2].x, r.q[2].y, r.q[2].z, r.q[2].w};
         const uint32_t hi[4] = {r.q[3].x, r.q[3].y, r.q[3].z, r.q[3].w};
@@ -142,6 +142,16 @@ __device__ __forceinline__ void init_mask_table(uint32_t* tab)
     }
     __syncthreads();
 }
+// the same table filled by one thread (host-side emulation harness under tests/, single-lane kernels)
+template <bool WIDE>
+__host__ __device__ inline void fill_mask_table_serial(uint32_t* tab)
+{
+    using L = Lay<WIDE>;
+    for(uint32_t i = 0; i < (L::kSyms + 1) * L::kRow; ++i) {
+        const uint32_t off = i / L::kRow, w = i % L::kRow;
+        tab[i] = w < L::kWords ? low_mask((int32_t)off - 32 * (int32_t)w) : 0u;
+    }
+}
 template <bool WIDE> struct MaskTabSize { static constexpr uint32_t value = (Lay<WIDE>::kSyms + 1) * Lay<WIDE>::kRow; };
 
 // Per-strand constants as plain scalars (wave-uniform, live in SGPRs).  Built from the kernel
@@ -155,7 +165,7 @@ struct StrandC {
     P c1, c2, c3, c4, n;      // C[A], C[C], C[G], C[T], N
 };
 template <class P>
-__device__ __forceinline__ StrandC<P> strand_consts(const FmStrand& s)
+__host__ __device__ __forceinline__ StrandC<P> strand_consts(const FmStrand& s)
 {
     StrandC<P> c;
     c.blocks = s.blocks; c.dollars = s.dollars; c.n_dollars = s.n_dollars;
@@ -164,7 +174,7 @@ __device__ __forceinline__ StrandC<P> strand_consts(const FmStrand& s)
 }
 // C[code + 1] without a table: three predicated adds of uniform deltas
 template <class P>
-__device__ __forceinline__ P pred_of(const StrandC<P>& s, uint32_t code)
+__host__ __device__ __forceinline__ P pred_of(const StrandC<P>& s, uint32_t code)
 {
     P v = s.c1;
     v += code >= 1 ? (s.c2 - s.c1) : 0;
@@ -174,7 +184,7 @@ __device__ __forceinline__ P pred_of(const StrandC<P>& s, uint32_t code)
 }
 // C[code + 2] (or N for T): upper end of the single-symbol interval
 template <class P>
-__device__ __forceinline__ P pred_next(const StrandC<P>& s, uint32_t code)
+__host__ __device__ __forceinline__ P pred_next(const StrandC<P>& s, uint32_t code)
 {
     P v = s.c2;
     v += code >= 1 ? (s.c3 - s.c2) : 0;
@@ -183,7 +193,7 @@ __device__ __forceinline__ P pred_next(const StrandC<P>& s, uint32_t code)
     return v;
 }
 template <class P>
-__device__ __forceinline__ uint64_t dollars_in_c(const StrandC<P>& s, uint64_t lo, uint64_t hi)
+__host__ __device__ __forceinline__ uint64_t dollars_in_c(const StrandC<P>& s, uint64_t lo, uint64_t hi)
 {
     uint64_t a = 0, b = s.n_dollars;
     while(a < b) { const uint64_t m = (a + b) >> 1; if(s.dollars[m] < lo) a = m + 1; else b = m; }
@@ -195,7 +205,7 @@ __device__ __forceinline__ uint64_t dollars_in_c(const StrandC<P>& s, uint64_t l
 
 // Occ over the first p symbols (p = idx + 1, 0 <= p <= N): RLBWT::getOcc (RLBWT.h:121-140)
 template <bool WIDE>
-__device__ __forceinline__ uint64_t occ_prefix(const StrandC<typename Lay<WIDE>::pos_t>& s, uint32_t code,
+__host__ __device__ __forceinline__ uint64_t occ_prefix(const StrandC<typename Lay<WIDE>::pos_t>& s, uint32_t code,
                                                typename Lay<WIDE>::pos_t p, const uint32_t* __restrict__ mtab)
 {
     using L = Lay<WIDE>;
@@ -216,7 +226,7 @@ template <class P> struct IvT { P lo, hi; };   // lower, upper; upper stored as-
 // wavefront are active (the correction kernel); in the position-parallel grid kernel some lane nearly always straddles
 // a block boundary, both branches would run, and the branch-free form is cheaper.
 template <bool WIDE, bool FAST2 = true>
-__device__ __forceinline__ IvT<typename Lay<WIDE>::pos_t> update_interval(const StrandC<typename Lay<WIDE>::pos_t>& s, uint32_t code,
+__host__ __device__ __forceinline__ IvT<typename Lay<WIDE>::pos_t> update_interval(const StrandC<typename Lay<WIDE>::pos_t>& s, uint32_t code,
                                                                           IvT<typename Lay<WIDE>::pos_t> iv,
                                                                           const uint32_t* __restrict__ mtab, uint32_t& n_blk)
 {
@@ -253,7 +263,7 @@ __device__ __forceinline__ IvT<typename Lay<WIDE>::pos_t> update_interval(const 
 
 // BWTAlgorithms::initInterval (BWTAlgorithms.h:136-140): Occ(b, N-1) is the symbol total.
 template <class P>
-__device__ __forceinline__ IvT<P> init_interval(const StrandC<P>& s, uint32_t code)
+__host__ __device__ __forceinline__ IvT<P> init_interval(const StrandC<P>& s, uint32_t code)
 {
     IvT<P> iv;
     iv.lo = pred_of(s, code);
@@ -298,7 +308,7 @@ struct WalkState {
     bool fwd_broken, rvc_broken;
 };
 template <class P>
-__device__ __forceinline__ WalkState<P> walk_init()
+__host__ __device__ __forceinline__ WalkState<P> walk_init()
 {
     WalkState<P> st;
     st.size = 0; st.counted = 0; st.n_rank = 0; st.n_blk = 0; st.fwd_broken = false; st.rvc_broken = false;
@@ -307,7 +317,7 @@ __device__ __forceinline__ WalkState<P> walk_init()
 }
 
 template <bool WIDE>
-__device__ __forceinline__ WalkState<typename Lay<WIDE>::pos_t>
+__host__ __device__ __forceinline__ WalkState<typename Lay<WIDE>::pos_t>
 walk_step(const StrandC<typename Lay<WIDE>::pos_t>& sf, const StrandC<typename Lay<WIDE>::pos_t>& sr, uint32_t c,
           uint32_t base_k, WalkState<typename Lay<WIDE>::pos_t> st, const uint32_t* __restrict__ mtab)
 {
@@ -346,7 +356,7 @@ walk_step(const StrandC<typename Lay<WIDE>::pos_t>& sf, const StrandC<typename L
 // Returns 0 (and leaves st untouched) when no table of size <= max_k exists.
 // ---------------------------------------------------------------------------------------
 template <bool WIDE, class Get>
-__device__ __forceinline__ uint32_t table_start(const FmIndexDev& fm, Get get, uint32_t max_k,
+__host__ __device__ __forceinline__ uint32_t table_start(const FmIndexDev& fm, Get get, uint32_t max_k,
                                                 WalkState<typename Lay<WIDE>::pos_t>& st)
 {
     using P = typename Lay<WIDE>::pos_t;
@@ -381,7 +391,7 @@ __device__ __forceinline__ uint32_t table_start(const FmIndexDev& fm, Get get, u
     return k;
 }
 
-template <class P> __device__ __forceinline__ int64_t iv_freq(const IvT<P>& iv) { return iv.lo <= iv.hi ? (int64_t)(iv.hi - iv.lo) + 1 : 0; }
+template <class P> __host__ __device__ __forceinline__ int64_t iv_freq(const IvT<P>& iv) { return iv.lo <= iv.hi ? (int64_t)(iv.hi - iv.lo) + 1 : 0; }
 template <class P> __device__ __forceinline__ lrsc_biinterval to_out(const IvT<P>& f, const IvT<P>& r)
 {
     lrsc_biinterval o;

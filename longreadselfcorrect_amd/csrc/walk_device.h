@@ -73,22 +73,22 @@ struct Leaf {                         // SAIOverlapNode3 + leafInfo, flattened
     uint8_t ext, alive;               // children: extension code; survival flag
 };
 
-template <class P> __device__ __forceinline__ int64_t isize(P lo, P hi) { return (int64_t)hi - (int64_t)lo + 1; }
+template <class P> __host__ __device__ __forceinline__ int64_t isize(P lo, P hi) { return (int64_t)hi - (int64_t)lo + 1; }
 
 // character `t` (0 = oldest) of the suffix of length l of a leaf's path
-template <class P> __device__ __forceinline__ uint32_t suf_char(const Leaf<P>& lf, uint32_t l, uint32_t t)
+template <class P> __host__ __device__ __forceinline__ uint32_t suf_char(const Leaf<P>& lf, uint32_t l, uint32_t t)
 {
     const uint32_t back = l - 1 - t;                     // distance from the newest character
     return back < 32 ? (uint32_t)(lf.suf_lo >> (2 * back)) & 3u : (uint32_t)(lf.suf_hi >> (2 * (back - 32))) & 3u;
 }
-template <class P> __device__ __forceinline__ void suf_push(Leaf<P>& lf, uint32_t c)
+template <class P> __host__ __device__ __forceinline__ void suf_push(Leaf<P>& lf, uint32_t c)
 {
     lf.suf_hi = (lf.suf_hi << 2) | (lf.suf_lo >> 62);
     lf.suf_lo = (lf.suf_lo << 2) | c;
 }
 
-__device__ __forceinline__ uint32_t path_get(const uint32_t* p, uint32_t i) { return (p[i >> 4] >> (2 * (i & 15))) & 3u; }
-__device__ __forceinline__ void path_set(uint32_t* p, uint32_t i, uint32_t c)
+__host__ __device__ __forceinline__ uint32_t path_get(const uint32_t* p, uint32_t i) { return (p[i >> 4] >> (2 * (i & 15))) & 3u; }
+__host__ __device__ __forceinline__ void path_set(uint32_t* p, uint32_t i, uint32_t c)
 {
     const uint32_t sh = 2 * (i & 15);
     p[i >> 4] = (p[i >> 4] & ~(3u << sh)) | (c << sh);

@@ -1,0 +1,1253 @@
+// walk_sm.h -- the per-read correction chain (PacBioSelfCorrectionProcess::initCorrect / correctByFMExtension,
+// PacBio/PacBioSelfCorrectionProcess.cpp:56-206) and the seed-to-seed FM-extension it drives
+// (LongReadSelfCorrectByOverlap, PacBio/LongReadCorrectByOverlap.cpp:17-878) as an explicit per-lane STATE MACHINE.
+//
+// Why a state machine: one lane owns one read, and the reads of a wavefront are at unrelated points of their chains.
+// Written as nested loops, every lane sits at a different program counter and the wavefront executes the lanes one
+// after the other (1.4 of 64 lanes active per instruction in round 1).  Here the control flow of the whole wavefront
+// is ONE loop:
+//
+//      loop:  R-phase   every lane that has a pending FM-index request (a pair of updateIntervals, or a k-mer
+//                        interval-table look-up) gets it answered -- all lanes in the same instructions
+//             sweep     a fixed sequence of `if(pc == X)` blocks; a lane runs the blocks its state selects until it
+//                        has the next request (lanes in the same state share the instructions)
+//
+// so that divergence is in data, not in control.  All rank queries of the path -- refineSAInterval / initialRootNode
+// (FS), SelectFreqsOfrange (SF), getFMIndexExtensions (EXT), the constructor's per-offset searches (PREP) -- go through
+// the R-phase; everything else is the reference's bookkeeping, restated once per state.
+//
+// The file is host/device neutral (no wavefront intrinsics): correct_sm.hip drives it on the GPU, the emulation
+// harness under tests/host_emul drives the very same code lane by lane on the CPU (test infrastructure only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "correct_dev.h"
+#include "walk_device.h"
+
+namespace lrsc {
+
+#define LRSC_SM __host__ __device__ inline
+
+enum : uint32_t { kReqNone = 0, kReqRank = 1, kReqTab = 2 };
+enum : uint32_t { kReqDoA = 1u, kReqDoB = 2u, kReqSwap = 4u };
+
+// A pending FM-index request of one lane.
+//   kReqRank: a = updateInterval(X, ca, a) if DoA, b = updateInterval(Y, cb, b) if DoB, with (X, Y) = (rBWT, BWT), or
+//             (BWT, rBWT) when Swap is set (SelectFreqsOfrange searches the k-mer itself, not its reverse).
+//   kReqTab:  entry `code` of k-mer table `tab` -> a = {fwd.lo, fwd.hi}, b = {rvc.lo, rvc.hi}
+template <class P>
+struct SmReq {
+    uint32_t kind, flags;
+    P a_lo, a_hi, b_lo, b_hi;
+    uint32_t ca, cb;
+    uint32_t tab, code;
+};
+
+enum : uint32_t {
+    // order = order of the blocks in sweep(); forward transitions are taken in the same sweep
+    PC_FS = 1,            // find_suffix over a leaf list: waiting for a table entry or a step
+    PC_SF,                // SelectFreqsOfrange
+    PC_ROOT_DONE,
+    PC_EXT,               // getFMIndexExtensions of leaf att_i: waiting for base att_b
+    PC_ATT_DONE,
+    PC_AFTER_SF_A,
+    PC_POST,
+    PC_AFTER_SF_B,
+    PC_PRUNE,
+    PC_STEP_ENTRY,
+    PC_WALK_END,
+    PC_NEXT,              // between walks: next target / yield / done
+    PC_PREP,              // constructor: per-offset searches
+    PC_BEGIN,             // interval "trees" + root
+    PC_ATT_ENTRY,
+    PC_ATT_LEAF,
+    PC_FINAL,
+    PC_DONE
+};
+
+// The R-phase for one lane: answers rq into res (a_lo, a_hi, b_lo, b_hi).  All lanes of a wavefront call this together.
+template <bool WIDE>
+__host__ __device__ __forceinline__ void sm_answer(const FmIndexDev& fm, const StrandC<typename Lay<WIDE>::pos_t>& sF,
+                                                   const StrandC<typename Lay<WIDE>::pos_t>& sR, const uint32_t* mtab,
+                                                   const SmReq<typename Lay<WIDE>::pos_t>& rq, SmReq<typename Lay<WIDE>::pos_t>& res,
+                                                   uint32_t& n_rank, uint32_t& n_blk, uint32_t& n_tab)
+{
+    using P = typename Lay<WIDE>::pos_t;
+    res.a_lo = rq.a_lo; res.a_hi = rq.a_hi; res.b_lo = rq.b_lo; res.b_hi = rq.b_hi;
+    if(rq.kind == kReqTab) {
+        const void* tabv = rq.tab == 0 ? fm.ktab[0].entries : rq.tab == 1 ? fm.ktab[1].entries : rq.tab == 2 ? fm.ktab[2].entries
+                         : rq.tab == 3 ? fm.ktab[3].entries : fm.ktab[4].entries;
+        if(WIDE) {
+            const uint4* t = reinterpret_cast<const uint4*>(tabv) + (uint64_t)rq.code * 2;
+            const uint4 a = t[0], b = t[1];
+            res.a_lo = (P)(((uint64_t)a.y << 32) | a.x); res.a_hi = (P)(((uint64_t)a.w << 32) | a.z);
+            res.b_lo = (P)(((uint64_t)b.y << 32) | b.x); res.b_hi = (P)(((uint64_t)b.w << 32) | b.z);
+        } else {
+            const uint4 a = reinterpret_cast<const uint4*>(tabv)[rq.code];
+            res.a_lo = (P)a.x; res.a_hi = (P)a.y; res.b_lo = (P)a.z; res.b_hi = (P)a.w;
+        }
+        n_tab += 1;
+    } else if(rq.kind == kReqRank) {
+        const bool swap = (rq.flags & kReqSwap) != 0;
+        // per-lane strand choice: (rBWT, BWT) or swapped
+        StrandC<P> SA, SB;
+        SA.blocks = swap ? sR.blocks : sF.blocks;   SB.blocks = swap ? sF.blocks : sR.blocks;
+        SA.dollars = swap ? sR.dollars : sF.dollars; SB.dollars = swap ? sF.dollars : sR.dollars;
+        SA.n_dollars = swap ? sR.n_dollars : sF.n_dollars; SB.n_dollars = swap ? sF.n_dollars : sR.n_dollars;
+        SA.c1 = swap ? sR.c1 : sF.c1; SA.c2 = swap ? sR.c2 : sF.c2; SA.c3 = swap ? sR.c3 : sF.c3; SA.c4 = swap ? sR.c4 : sF.c4; SA.n = swap ? sR.n : sF.n;
+        SB.c1 = swap ? sF.c1 : sR.c1; SB.c2 = swap ? sF.c2 : sR.c2; SB.c3 = swap ? sF.c3 : sR.c3; SB.c4 = swap ? sF.c4 : sR.c4; SB.n = swap ? sF.n : sR.n;
+        if(rq.flags & kReqDoA) {
+            const IvT<P> o = update_interval<WIDE, false>(SA, rq.ca, IvT<P>{rq.a_lo, rq.a_hi}, mtab, n_blk);
+            res.a_lo = o.lo; res.a_hi = o.hi; n_rank += 2;
+        }
+        if(rq.flags & kReqDoB) {
+            const IvT<P> o = update_interval<WIDE, false>(SB, rq.cb, IvT<P>{rq.b_lo, rq.b_hi}, mtab, n_blk);
+            res.b_lo = o.lo; res.b_hi = o.hi; n_rank += 2;
+        }
+    }
+}
+
+template <bool WIDE>
+struct ReadSM {
+    using P = typename Lay<WIDE>::pos_t;
+    using LeafT = Leaf<P>;
+
+    // ---- wave-uniform context (pointers into kernel arguments) ----
+    const FmIndexDev* __restrict__ fm;
+    const CorrectArgs* __restrict__ A;
+    StrandC<P> sF, sR;
+
+    // ---- the read ----
+    uint32_t r;
+    const uint8_t* read;
+    const int32_t* seeds;
+    uint32_t n_seeds, rlen;
+    uint8_t* out;
+    uint32_t* piece_start;
+    uint8_t* ws;
+    ReadWork rw;
+    // chain state (pieceVec.back()'s SeedFeature fields + iterTarget)
+    int32_t S_seedLen, S_end, S_endBest, S_maxFixed;
+    bool S_isRepeat;
+    uint32_t it;
+    int32_t next, firstType;
+    uint32_t out_len, n_pieces;
+    int64_t correctedLen, totalWalkNum, highErrorNum, exceedDepthNum, exceedLeaveNum, FMNum, DPNum, seedDis;
+    int32_t error;
+    uint32_t state;               // kReadDone / kReadParked / kReadYield
+    uint32_t walks_here;
+    uint64_t steps, steps0;
+    // current walk geometry
+    int32_t T_start, T_len, interval, k, trg_len;
+    bool T_isRepeat, rtou;
+    uint32_t Lq, initk;
+    uint64_t min_SA_threshold, maxIndelSize, maxLength, minLength, currentLength, currentKmerSize;
+    uint32_t maxOverlap;
+    uint32_t n_cur, n_nxt, n_results, n9f, n9r;
+    uint32_t slot_free;           // free ring/path slots (bit mask; a leaf's ring and path slot ids are always equal)
+    bool ended;
+    // ---- state machine ----
+    uint32_t pc;
+    SmReq<P> req;
+    // FS
+    uint32_t fs_list, fs_n, fs_j, fs_len, fs_t, fs_ret;
+    bool fs_start, fs_fb, fs_rb, fs_setk;
+    P fs_flo, fs_fhi, fs_rlo, fs_rhi;
+    uint64_t fs_suf_lo, fs_suf_hi;
+    // SF
+    uint32_t sf_list, sf_n, sf_j, sf_t, sf_i, sf_ret, sf_phase;
+    uint32_t sf_LB, sf_UB;
+    int32_t sf_max;
+    uint64_t sf_result;
+    bool sf_start, sf_fb, sf_rb;
+    P sf_flo, sf_fhi, sf_rlo, sf_rhi;
+    uint64_t sf_suf_lo, sf_suf_hi;
+    // ATT / EXT
+    uint32_t att_no, att_i, att_b;
+    double att_minErr;
+    P ex_flo[4], ex_fhi[4], ex_rlo[4], ex_rhi[4];
+    // PREP
+    uint32_t prep_i, prep_s, prep_kmax;
+    bool prep_start, prep_term, prep_fb, prep_rb;
+    P prep_flo, prep_fhi, prep_rlo, prep_rhi;
+    // accounting
+    uint32_t n_rank, n_blk, n_tab;
+
+    // ---- workspace views ----
+    LRSC_SM SortItem* it9f() const { return reinterpret_cast<SortItem*>(ws + rw.o_item9f); }
+    LRSC_SM SortItem* it9r() const { return reinterpret_cast<SortItem*>(ws + rw.o_item9r); }
+    LRSC_SM uint16_t* next9f() const { return reinterpret_cast<uint16_t*>(ws + rw.o_next9f); }
+    LRSC_SM uint16_t* next9r() const { return reinterpret_cast<uint16_t*>(ws + rw.o_next9r); }
+    LRSC_SM uint16_t* head9f() const { return reinterpret_cast<uint16_t*>(ws + rw.o_head9); }
+    LRSC_SM uint16_t* head9r() const { return reinterpret_cast<uint16_t*>(ws + rw.o_head9) + 256; }
+    LRSC_SM uint16_t* head5() const { return reinterpret_cast<uint16_t*>(ws + rw.o_head5); }
+    LRSC_SM uint16_t* next5() const { return reinterpret_cast<uint16_t*>(ws + rw.o_next5); }
+    LRSC_SM uint8_t* flags5() const { return ws + rw.o_flags5; }
+    LRSC_SM P* term() const { return reinterpret_cast<P*>(ws + rw.o_term); }
+    LRSC_SM LeafT* cur() const { return reinterpret_cast<LeafT*>(ws + rw.o_leaves); }
+    LRSC_SM LeafT* nxt() const { return reinterpret_cast<LeafT*>(ws + rw.o_leaves) + 32; }
+    LRSC_SM LeafT* leaves(uint32_t list) const { return list ? nxt() : cur(); }
+    LRSC_SM double* rings() const { return reinterpret_cast<double*>(ws + rw.o_rings); }
+    LRSC_SM uint32_t* paths() const { return reinterpret_cast<uint32_t*>(ws + rw.o_paths); }
+    LRSC_SM uint32_t* rpaths() const { return reinterpret_cast<uint32_t*>(ws + rw.o_paths) + (uint64_t)32 * rw.pathw; }
+    LRSC_SM WalkResultRec* results() const { return reinterpret_cast<WalkResultRec*>(ws + rw.o_results); }
+    LRSC_SM uint8_t* q() const { return ws + rw.o_query; }
+    LRSC_SM uint32_t* best() const { return reinterpret_cast<uint32_t*>(ws + rw.o_best); }
+    LRSC_SM uint8_t* dpq() const { return ws + rw.o_dpq; }
+
+    LRSC_SM uint32_t seedSize() const { return A->seed_size; }
+    LRSC_SM uint32_t minOverlap() const { return A->min_overlap; }
+
+    // ---- request helpers ----------------------------------------------------------------------------------
+    LRSC_SM void req_rank(P alo, P ahi, uint32_t ca, bool doa, P blo, P bhi, uint32_t cb, bool dob, bool swap)
+    {
+        req.kind = kReqRank;
+        req.flags = (doa ? kReqDoA : 0u) | (dob ? kReqDoB : 0u) | (swap ? kReqSwap : 0u);
+        req.a_lo = alo; req.a_hi = ahi; req.b_lo = blo; req.b_hi = bhi; req.ca = ca; req.cb = cb;
+    }
+    LRSC_SM void req_tab(uint32_t tab, uint32_t code) { req.kind = kReqTab; req.tab = tab; req.code = code; }
+
+    // largest table with k <= max_k (-1: none)
+    LRSC_SM int best_table(uint32_t max_k) const
+    {
+        int b = -1;
+        if(fm->ktab[0].k != 0 && fm->ktab[0].k <= max_k) b = 0;
+        if(fm->ktab[1].k != 0 && fm->ktab[1].k <= max_k) b = 1;
+        if(fm->ktab[2].k != 0 && fm->ktab[2].k <= max_k) b = 2;
+        if(fm->ktab[3].k != 0 && fm->ktab[3].k <= max_k) b = 3;
+        if(fm->ktab[4].k != 0 && fm->ktab[4].k <= max_k) b = 4;
+        return b;
+    }
+    LRSC_SM uint32_t table_k(int t) const
+    {
+        return t == 0 ? fm->ktab[0].k : t == 1 ? fm->ktab[1].k : t == 2 ? fm->ktab[2].k : t == 3 ? fm->ktab[3].k : fm->ktab[4].k;
+    }
+    // characters [t0, t0 + k) (0 = oldest) of the suffix of length l of a packed path, first character in the high bits
+    static LRSC_SM uint32_t suf_code(uint64_t lo, uint64_t hi, uint32_t l, uint32_t t0, uint32_t k)
+    {
+        uint32_t code = 0;
+        for(uint32_t t = 0; t < k; ++t) {
+            const uint32_t back = l - 1 - (t0 + t);
+            const uint32_t c = back < 32 ? (uint32_t)(lo >> (2 * back)) & 3u : (uint32_t)(hi >> (2 * (back - 32))) & 3u;
+            code = (code << 2) | c;
+        }
+        return code;
+    }
+    static LRSC_SM uint32_t suf_at(uint64_t lo, uint64_t hi, uint32_t l, uint32_t t)
+    {
+        const uint32_t back = l - 1 - t;
+        return back < 32 ? (uint32_t)(lo >> (2 * back)) & 3u : (uint32_t)(hi >> (2 * (back - 32))) & 3u;
+    }
+
+    // =========================================================================================================
+    // FS: findInterval of the suffix of length fs_len of every leaf of a list (refineSAInterval .cpp:355-369,
+    // initialRootNode :108-124); fwd = reverse(kmer) in the rBWT, rvc = revcomp(kmer) in the BWT.
+    // =========================================================================================================
+    LRSC_SM void fs_begin(uint32_t list, uint32_t n, uint32_t len, uint32_t ret, bool set_k)
+    {
+        fs_list = list; fs_n = n; fs_len = len; fs_ret = ret; fs_j = 0; fs_start = true; fs_setk = set_k;
+        pc = PC_FS;
+        fs_advance();
+    }
+    LRSC_SM void fs_advance()
+    {
+        while(true) {
+            if(fs_start) {
+                if(fs_j >= fs_n) {
+                    if(fs_setk) currentKmerSize = fs_len;
+                    pc = fs_ret;
+                    return;
+                }
+                const LeafT& lf = leaves(fs_list)[fs_j];
+                fs_suf_lo = lf.suf_lo; fs_suf_hi = lf.suf_hi;
+                fs_start = false;
+                fs_fb = false; fs_rb = false;
+                const int tb = best_table(fs_len);
+                if(tb >= 0) {
+                    const uint32_t tk = table_k(tb);
+                    fs_t = tk;
+                    req_tab((uint32_t)tb, suf_code(fs_suf_lo, fs_suf_hi, fs_len, 0, tk));
+                    fs_t |= 0x80000000u;                         // marks "table entry pending"
+                    return;
+                }
+                // no table: the first character is initInterval on both strands
+                const uint32_t c = suf_at(fs_suf_lo, fs_suf_hi, fs_len, 0);
+                const IvT<P> f = init_interval<P>(sF, c), rr = init_interval<P>(sR, 3u - c);
+                fs_flo = f.lo; fs_fhi = f.hi; fs_rlo = rr.lo; fs_rhi = rr.hi;
+                fs_t = 1;
+                n_rank += 2;
+            }
+            if(fs_t < fs_len && !(fs_fb && fs_rb)) {
+                const uint32_t c = suf_at(fs_suf_lo, fs_suf_hi, fs_len, fs_t);
+                req_rank(fs_flo, fs_fhi, c, !fs_fb, fs_rlo, fs_rhi, 3u - c, !fs_rb, false);
+                return;
+            }
+            LeafT& lf = leaves(fs_list)[fs_j];
+            lf.flo = fs_flo; lf.fhi = fs_fhi; lf.rlo = fs_rlo; lf.rhi = fs_rhi;
+            ++fs_j;
+            fs_start = true;
+        }
+    }
+    LRSC_SM void fs_result(const SmReq<P>& res)
+    {
+        if(fs_t & 0x80000000u) {                                 // table entry
+            fs_t &= 0x7FFFFFFFu;
+            fs_flo = res.a_lo; fs_fhi = res.a_hi; fs_rlo = res.b_lo; fs_rhi = res.b_hi;
+            fs_fb = fs_flo > fs_fhi; fs_rb = fs_rlo > fs_rhi;
+        } else {
+            if(!fs_fb) { fs_flo = res.a_lo; fs_fhi = res.a_hi; fs_fb = fs_flo > fs_fhi; }
+            if(!fs_rb) { fs_rlo = res.b_lo; fs_rhi = res.b_hi; fs_rb = fs_rlo > fs_rhi; }
+            ++fs_t;
+        }
+        fs_advance();
+    }
+
+    // =========================================================================================================
+    // SF: SelectFreqsOfrange (.cpp:281-331).  Phase 1 = findInterval(BWT, startkmer) / findInterval(RBWT,
+    // complement(startkmer)) per leaf, startkmer = the last LB characters of the leaf's suffix, searched from its last
+    // character backwards: exactly the k-mer table state of w[t] = 3 - x_t (x_0 = newest character), fwd <-> rvc swapped.
+    // =========================================================================================================
+    LRSC_SM void sf_begin(uint32_t list, uint32_t n, uint64_t LB, uint64_t UB, uint32_t ret)
+    {
+        sf_list = list; sf_n = n; sf_LB = (uint32_t)LB; sf_UB = (uint32_t)UB; sf_ret = ret;
+        sf_phase = 1; sf_j = 0; sf_start = true; sf_max = 0;
+        pc = PC_SF;
+        sf_advance();
+    }
+    LRSC_SM void sf_store_leaf()
+    {
+        LeafT& lf = leaves(sf_list)[sf_j];
+        lf.tflo = sf_flo; lf.tfhi = sf_fhi; lf.trlo = sf_rlo; lf.trhi = sf_rhi;
+        lf.tmpFreq = (int)(isize(sf_flo, sf_fhi) + isize(sf_rlo, sf_rhi));
+        if(lf.tmpFreq > sf_max) sf_max = lf.tmpFreq;
+    }
+    LRSC_SM void sf_finish(uint64_t result) { sf_result = result; pc = sf_ret; }
+    LRSC_SM void sf_advance()
+    {
+        const uint32_t U = sf_UB, Lw = sf_LB;
+        while(true) {
+            if(sf_phase == 1) {
+                if(sf_start) {
+                    if(sf_j >= sf_n) {
+                        if(sf_max - (int)A->freqs_of_kmer_size[sf_LB] < 5) { sf_finish(sf_LB); return; }
+                        if(sf_UB == sf_LB) { sf_finish(sf_UB); return; }
+                        sf_phase = 2; sf_i = 1; sf_j = 0; sf_max = 0;
+                        continue;
+                    }
+                    const LeafT& lf = leaves(sf_list)[sf_j];
+                    sf_suf_lo = lf.suf_lo; sf_suf_hi = lf.suf_hi;
+                    sf_start = false; sf_fb = false; sf_rb = false;
+                    const int tb = best_table(Lw);
+                    if(tb >= 0) {
+                        // w[t] = 3 - x_t, x_t = character at distance t from the newest one
+                        const uint32_t tk = table_k(tb);
+                        uint32_t code = 0;
+                        for(uint32_t t = 0; t < tk; ++t) {
+                            const uint32_t x = t < 32 ? (uint32_t)(sf_suf_lo >> (2 * t)) & 3u : (uint32_t)(sf_suf_hi >> (2 * (t - 32))) & 3u;
+                            code = (code << 2) | (3u - x);
+                        }
+                        sf_t = tk | 0x80000000u;
+                        req_tab((uint32_t)tb, code);
+                        return;
+                    }
+                    const uint32_t x0 = (uint32_t)sf_suf_lo & 3u;
+                    const IvT<P> f = init_interval<P>(sR, x0), rr = init_interval<P>(sF, 3u - x0);
+                    sf_flo = f.lo; sf_fhi = f.hi; sf_rlo = rr.lo; sf_rhi = rr.hi;
+                    sf_t = 1;
+                    n_rank += 2;
+                }
+                if(sf_t < Lw && !(sf_fb && sf_rb)) {
+                    const uint32_t t = sf_t;
+                    const uint32_t c = t < 32 ? (uint32_t)(sf_suf_lo >> (2 * t)) & 3u : (uint32_t)(sf_suf_hi >> (2 * (t - 32))) & 3u;
+                    req_rank(sf_flo, sf_fhi, c, !sf_fb, sf_rlo, sf_rhi, 3u - c, !sf_rb, true);
+                    return;
+                }
+                sf_store_leaf();
+                ++sf_j;
+                sf_start = true;
+            } else {
+                // phase 2: extend every leaf's pair by one more (older) character, no validity check (.cpp:317-318)
+                if(sf_j >= sf_n) {
+                    if(sf_max - (int)A->freqs_of_kmer_size[sf_LB + sf_i] < 5) { sf_finish(sf_LB + sf_i); return; }
+                    ++sf_i;
+                    if(sf_i > sf_UB - sf_LB) { sf_finish(sf_UB); return; }
+                    sf_j = 0; sf_max = 0;
+                    continue;
+                }
+                const LeafT& lf = leaves(sf_list)[sf_j];
+                const uint32_t b = suf_char(lf, U, (uint32_t)(sf_UB - sf_LB - sf_i));
+                sf_flo = lf.tflo; sf_fhi = lf.tfhi; sf_rlo = lf.trlo; sf_rhi = lf.trhi;
+                req_rank(sf_flo, sf_fhi, b, true, sf_rlo, sf_rhi, 3u - b, true, true);
+                return;
+            }
+        }
+    }
+    LRSC_SM void sf_result_in(const SmReq<P>& res)
+    {
+        if(sf_phase == 1) {
+            if(sf_t & 0x80000000u) {
+                // table entry of w: fwd = rBWT state (our r), rvc = BWT state (our f)
+                sf_t &= 0x7FFFFFFFu;
+                sf_rlo = res.a_lo; sf_rhi = res.a_hi; sf_flo = res.b_lo; sf_fhi = res.b_hi;
+                sf_fb = sf_flo > sf_fhi; sf_rb = sf_rlo > sf_rhi;
+            } else {
+                if(!sf_fb) { sf_flo = res.a_lo; sf_fhi = res.a_hi; sf_fb = sf_flo > sf_fhi; }
+                if(!sf_rb) { sf_rlo = res.b_lo; sf_rhi = res.b_hi; sf_rb = sf_rlo > sf_rhi; }
+                ++sf_t;
+            }
+        } else {
+            sf_flo = res.a_lo; sf_fhi = res.a_hi; sf_rlo = res.b_lo; sf_rhi = res.b_hi;
+            sf_store_leaf();
+            ++sf_j;
+        }
+        sf_advance();
+    }
+
+    // =========================================================================================================
+    // rank-free pieces of the walk (restated from walk_device.h's Walk, which the per-walk kernels keep using)
+    // =========================================================================================================
+    LRSC_SM bool isInsufficientFreqs(const LeafT* lv, uint32_t n) const             // .cpp:334-352
+    {
+        uint64_t highfreqscount = 0;
+        const uint64_t cov = A->pb_coverage;
+        for(uint32_t i = 0; i < n; ++i) {
+            const int highfreqThreshold = cov > 60 ? (int)((uint64_t)(cov / 60) * 3) : 3;
+            if(lv[i].kmerFrequency > highfreqThreshold) highfreqscount++;
+        }
+        if(highfreqscount == 0) return true;
+        else if(highfreqscount <= 2 && n >= 5) return true;
+        else if(highfreqscount <= 1 && n >= 3) return true;
+        return false;
+    }
+
+    LRSC_SM bool ismatchedbykmer(uint32_t code5, bool fvalid, bool rvalid) const      // .cpp:787-821
+    {
+        const uint64_t startSeedIdx = (uint64_t)(((int)currentLength - (int)maxIndelSize) > 0 ? ((int)currentLength - (int)maxIndelSize) : 0);
+        const uint64_t largeSeedIdx = currentLength + maxIndelSize;
+        const uint16_t* n5 = next5();
+        const uint8_t* f5 = flags5();
+        for(uint32_t j = head5()[code5]; j != 0xFFFFu; j = n5[j]) {
+            if(j >= startSeedIdx && j <= largeSeedIdx) {
+                const uint32_t fl = f5[j];
+                if((fvalid && (fl & 1)) || (rvalid && (fl & 2))) return true;
+            }
+        }
+        return false;
+    }
+
+    // the acceptance ladder of getFMIndexExtensions (.cpp:700-784) over the four extension pairs in ex_*
+    LRSC_SM uint32_t ext_mask(const LeafT& lf, int* freq) const
+    {
+        const uint64_t IntervalSizeCutoff = min_SA_threshold;
+        uint64_t totalcount = 0;
+        int maxfreqsofleave = 0;
+        for(uint32_t b = 0; b < 4; ++b) {
+            freq[b] = (int)(isize(ex_flo[b], ex_fhi[b]) + isize(ex_rlo[b], ex_rhi[b]));
+            totalcount += (uint64_t)(int64_t)freq[b];
+            if(freq[b] > maxfreqsofleave) maxfreqsofleave = freq[b];
+        }
+        uint32_t mask = 0;
+        const bool isHomopolymer = lf.tailLetterCount >= 3;
+        for(uint32_t b = 0; b < 4; ++b) {
+            const uint64_t kmerFreq = (uint64_t)(int64_t)freq[b];
+            const double kmerRatioNotPass = 2;
+            double kmerRatioCutoff = 0;
+            const double kmerRatio = (double)kmerFreq / (double)maxfreqsofleave;
+            const bool efv = ex_flo[b] <= ex_fhi[b], erv = ex_rlo[b] <= ex_rhi[b];
+            const uint32_t code5 = (uint32_t)(((lf.suf_lo << 2) | b) & 0x3FFu);
+            const bool isMatchedBy5mer = ismatchedbykmer(code5, efv, erv);
+            const bool isFreqPass = kmerFreq >= IntervalSizeCutoff;
+            const bool isLowCoverage = totalcount >= IntervalSizeCutoff + 2;
+            const bool isRepeat = maxfreqsofleave > 100;
+            const bool isHighlyRepeat = maxfreqsofleave > 150;
+            const bool isLowlyRepeat = maxfreqsofleave > 50;
+            if(isMatchedBy5mer && isHighlyRepeat) kmerRatioCutoff = 0.125;
+            else if(isMatchedBy5mer && isLowlyRepeat) kmerRatioCutoff = 0.2;
+            else if(isFreqPass) kmerRatioCutoff = 0.25;
+            else if(isLowCoverage) kmerRatioCutoff = 0.6;
+            else kmerRatioCutoff = kmerRatioNotPass;
+            if(isHomopolymer && isRepeat) kmerRatioCutoff = kmerRatioCutoff > 0.3 ? kmerRatioCutoff : 0.3;
+            else if(isHomopolymer) kmerRatioCutoff = kmerRatioCutoff > 0.6 ? kmerRatioCutoff : 0.6;
+            if(kmerRatio >= kmerRatioCutoff) mask |= 1u << b;
+        }
+        return mask;
+    }
+
+    LRSC_SM void free_leaf_slots(const LeafT& lf) { slot_free |= 1u << lf.ring; }
+    LRSC_SM uint32_t alloc_slot()
+    {
+        uint32_t s = 0;
+        while(s < 31 && !((slot_free >> s) & 1u)) ++s;          // a free slot always exists: <= 32 leaves share 32 slots
+        slot_free &= ~(1u << s);
+        return s;
+    }
+
+    LRSC_SM uint32_t kmer_code(uint32_t i) const
+    {
+        const uint8_t* qq = q();
+        uint32_t c = 0;
+        for(uint32_t t = 0; t < seedSize(); ++t) c = (c << 2) | qq[i + t];
+        return c;
+    }
+
+    LRSC_SM bool isSupportedByNewSeed(LeafT& nd, uint64_t smallSeedIdx, uint64_t largeSeedIdx)     // .cpp:566-635
+    {
+        const uint32_t seedSz = seedSize();
+        const uint64_t seedIdxOffset = nd.lastOverlapLen < currentLength - seedSz ? (uint64_t)seedSz : currentLength - nd.lastOverlapLen;
+        const uint64_t cand = nd.lastSeedIdx + seedIdxOffset;
+        const uint64_t startSeedIdx = smallSeedIdx > cand ? smallSeedIdx : cand;
+        bool isNewSeedFound = false;
+        const bool fv = nd.flo <= nd.fhi, rv = nd.rlo <= nd.rhi;
+        const uint32_t mask9 = seedSz >= 16 ? 0xFFFFFFFFu : ((1u << (2 * seedSz)) - 1u);
+        const uint32_t code9 = (uint32_t)nd.suf_lo & mask9;
+        const uint32_t hb = (code9 ^ (code9 >> 9)) & 255u;
+        const SortItem* i9f = it9f(); const SortItem* i9r = it9r();
+        const uint16_t* nf = next9f(); const uint16_t* nr = next9r();
+        uint32_t jf = fv ? head9f()[hb] : 0xFFFFu;
+        uint32_t jr = rv ? head9r()[hb] : 0xFFFFu;
+        while(jf != 0xFFFFu && kmer_code(i9f[jf].val) != code9) jf = nf[jf];
+        while(jr != 0xFFFFu && kmer_code(i9r[jr].val) != code9) jr = nr[jr];
+        int minIdxDiff = 10000;
+        const uint64_t currSeedIdx = currentLength - seedSz;
+        while(jf != 0xFFFFu || jr != 0xFFFFu) {
+            const uint64_t vf = jf != 0xFFFFu ? i9f[jf].val : 0, vr = jr != 0xFFFFu ? i9r[jr].val : 0;
+            if(fv && jf != 0xFFFFu && vf >= startSeedIdx && vf <= largeSeedIdx) {
+                const int d = abs((int)vf - (int)currSeedIdx);
+                if(d < minIdxDiff) { nd.lastSeedIdx = vf; nd.queryOverlapLen = vf + seedSz; minIdxDiff = d; }
+                nd.lastOverlapLen = currentLength;
+                nd.currOverlapLen = currentLength;
+                isNewSeedFound = true;
+            } else if(rv && jr != 0xFFFFu && vr >= startSeedIdx && vr <= largeSeedIdx) {
+                const int d = abs((int)currSeedIdx - (int)vr);
+                if(d < minIdxDiff) { nd.lastSeedIdx = vr; nd.queryOverlapLen = vr + seedSz; minIdxDiff = d; }
+                nd.lastOverlapLen = currentLength;
+                nd.currOverlapLen = currentLength;
+                isNewSeedFound = true;
+            }
+            if(jf != 0xFFFFu) { jf = nf[jf]; while(jf != 0xFFFFu && kmer_code(i9f[jf].val) != code9) jf = nf[jf]; }
+            if(jr != 0xFFFFu) { jr = nr[jr]; while(jr != 0xFFFFu && kmer_code(i9r[jr].val) != code9) jr = nr[jr]; }
+        }
+        if(isNewSeedFound) nd.totalSeeds++;
+        return isNewSeedFound;
+    }
+
+    LRSC_SM double computeErrorRate(LeafT& nd, const double* parent_ring) const                  // .cpp:638-664
+    {
+        const uint64_t localK = 100;
+        double matchedLen = (double)nd.totalSeeds + seedSize() - 1;
+        matchedLen += nd.numRedeemSeed;
+        const double totalLen = (double)nd.currOverlapLen;
+        const double unmatchedLen = totalLen - matchedLen;
+        double currErrorRate = unmatchedLen / totalLen;
+        nd.globalErr = currErrorRate;
+        const uint32_t totalsize = nd.hist_size + 1;
+        nd.hist_size = totalsize;
+        if(totalsize >= localK) {
+            const double old = parent_ring[(totalsize - localK) % 100];
+            currErrorRate = (currErrorRate * totalLen - old * (totalLen - localK)) / localK;
+        }
+        nd.localErr = currErrorRate;
+        return currErrorRate;
+    }
+
+    LRSC_SM void PrunedBySeedSupport()                                                          // .cpp:491-563
+    {
+        const uint32_t seedSz = seedSize();
+        const double PacBioErrorRate = A->pacbio_error_rate;
+        const uint64_t currSeedIdx = currentLength - seedSz;
+        const uint64_t indelOffset = seedSz + maxIndelSize;
+        const uint64_t smallSeedIdx = currSeedIdx <= indelOffset ? 0 : currSeedIdx - indelOffset;
+        const uint64_t largeSeedIdx = (currSeedIdx + indelOffset) >= (Lq - seedSz) ? (Lq - seedSz) : currSeedIdx + indelOffset;
+        LeafT* nx = nxt(); const LeafT* cu = cur();
+        for(uint32_t c = 0; c < n_nxt; ++c) {
+            LeafT& leaf = nx[c];
+            bool isNewSeedFound = false;
+            if(currentLength - leaf.lastOverlapLen > seedSz || currentLength - leaf.lastOverlapLen <= 1) {
+                const uint64_t preSeedIdx = leaf.lastSeedIdx;
+                isNewSeedFound = isSupportedByNewSeed(leaf, smallSeedIdx, largeSeedIdx);
+                if(isNewSeedFound) {
+                    if(currSeedIdx + (uint64_t)(int64_t)leaf.lastSeedIdxOffset - preSeedIdx > seedSz)
+                        leaf.numRedeemSeed += (seedSz - 1) * PacBioErrorRate;
+                    leaf.lastSeedIdxOffset = (int)leaf.lastSeedIdx - (int)currSeedIdx;
+                } else {
+                    const uint64_t v = currSeedIdx + (uint64_t)(int64_t)leaf.lastSeedIdxOffset - leaf.lastSeedIdx;
+                    if(v % seedSz == 1) leaf.numOfErrors++;
+                    else if(v > (uint64_t)seedSz - 1) leaf.numRedeemSeed += 1 - PacBioErrorRate;
+                }
+            } else
+                leaf.numRedeemSeed += 1 - PacBioErrorRate;
+            const double* pring = rings() + (uint64_t)cu[leaf.parent].ring * 100;
+            const double currErrorRate = computeErrorRate(leaf, pring);
+            if(currErrorRate > 0.25) leaf.alive = 0;
+        }
+    }
+
+    LRSC_SM void terminated_leaf(LeafT& lf, const uint32_t* pw, uint32_t plen, int extra)         // .cpp:825-878
+    {
+        const bool fvalid = lf.flo <= lf.fhi, rvalid = lf.rlo <= lf.rhi;
+        const uint64_t i0 = (uint64_t)(lf.res_second > 0 ? lf.res_second : 0);
+        int hit = -1;
+        const P* tm = term();
+        for(uint64_t i = i0; i <= (uint64_t)trg_len - (int)minOverlap(); i++) {
+            const P* t = tm + i * 4;
+            const bool isFwdTerminated = fvalid && lf.flo >= t[0] && lf.fhi <= t[1];
+            const bool isRvcTerminated = rvalid && lf.rlo >= t[2] && lf.rhi <= t[3];
+            if(isFwdTerminated || isRvcTerminated) {
+                hit = (int)i;
+                if(lf.res_first == -1) {
+                    if(n_results >= kMaxResults) { error = LRSC_WALK_ERR_RESULTS; return; }
+                    ++n_results;
+                    lf.res_first = (int)n_results;
+                }
+                lf.res_second = (int)i;
+            }
+        }
+        if(hit < 0) return;
+        WalkResultRec& rr = results()[lf.res_first - 1];
+        rr.error_rate = lf.globalErr;
+        rr.match_i = (uint32_t)hit;
+        uint32_t* dst = rpaths() + (uint64_t)(lf.res_first - 1) * rw.pathw;
+        const uint32_t nw = (plen + 15) >> 4;
+        for(uint32_t kk = 0; kk < nw; ++kk) dst[kk] = pw[kk];
+        uint32_t len = plen;
+        if(extra >= 0) { path_set(dst, len, (uint32_t)extra); ++len; }
+        rr.path_len = len;
+    }
+
+    // interval "trees" (IntervalTree.cpp:4-48 -> k-mer chains in std::sort's order) + the root's bookkeeping
+    LRSC_SM void begin_walk()
+    {
+        const uint32_t seedSz = seedSize();
+        const uint8_t* qq = q();
+        const uint32_t n9_all = Lq >= seedSz ? Lq - seedSz + 1 : 0;
+        for(int strand = 0; strand < 2; ++strand) {
+            SortItem* itx = strand ? it9r() : it9f();
+            uint16_t* head = strand ? head9r() : head9f();
+            uint16_t* nextp = strand ? next9r() : next9f();
+            uint32_t n = 0;
+            for(uint32_t i = 0; i < n9_all; ++i)
+                if(itx[i].key != kNoKey) { if(n != i) itx[n] = itx[i]; ++n; }
+            introsort(itx, (int64_t)n);
+            for(uint32_t b = 0; b < 256; ++b) head[b] = 0xFFFFu;
+            for(uint32_t j = n; j-- > 0;) {                       // prepend walking backwards: chains keep the post-sort order
+                const uint32_t code = kmer_code(itx[j].val);
+                const uint32_t hb = (code ^ (code >> 9)) & 255u;
+                nextp[j] = head[hb];
+                head[hb] = (uint16_t)j;
+            }
+            if(strand) n9r = n; else n9f = n;
+        }
+        uint16_t* h5 = head5(); uint16_t* n5p = next5(); const uint8_t* f5 = flags5();
+        for(uint32_t c = 0; c < 1024; ++c) h5[c] = 0xFFFFu;
+        const uint32_t n5 = Lq >= 5 ? Lq - 5 + 1 : 0;
+        for(uint32_t i = n5; i-- > 0;) {
+            if(f5[i] == 0) continue;
+            uint32_t code = 0;
+            for(uint32_t t = 0; t < 5; ++t) code = (code << 2) | qq[i + t];
+            n5p[i] = h5[code];
+            h5[code] = (uint16_t)i;
+        }
+        // root (initialRootNode, .cpp:108-124; leafInfo ctor, .h:156-171)
+        slot_free = 0xFFFFFFFEu;
+        LeafT& root = cur()[0];
+        root.suf_lo = 0; root.suf_hi = 0;
+        for(uint32_t t = 0; t < initk; ++t) suf_push(root, qq[t]);
+        root.lastOverlapLen = root.currOverlapLen = root.queryOverlapLen = initk;
+        currentLength = currentKmerSize = initk;
+        root.lastSeedIdx = (uint64_t)initk - seedSz;
+        root.totalSeeds = (uint64_t)initk - seedSz + 1;
+        root.numOfErrors = 0;
+        root.numRedeemSeed = 0;
+        root.localErr = 0; root.globalErr = 0; root.hist_size = 1;
+        root.lastSeedIdxOffset = 0;
+        root.res_first = -1; root.res_second = -1;
+        root.tailLetter = qq[initk - 1];
+        root.tailLetterCount = 0;
+        for(uint32_t t = initk; t-- > 0;) { if(qq[t] == root.tailLetter) root.tailLetterCount++; else break; }
+        root.ring = 0; root.path = 0; root.parent = 0; root.ext = 0; root.alive = 1;
+        root.path_len = initk;
+        rings()[0] = 0.0;
+        uint32_t* p0 = paths();
+        for(uint32_t t = 0; t < initk; ++t) path_set(p0, t, qq[t]);
+        n_cur = 1; n_nxt = 0; n_results = 0;
+        ended = false;
+        fs_begin(0, 1, initk, PC_ROOT_DONE, false);
+    }
+
+    // attempToExtend's prologue (.cpp:373-398): drop leaves whose local error rate is far from the best one
+    LRSC_SM void att_entry()
+    {
+        const uint64_t localK = 100;
+        LeafT* cu = cur();
+        double minimumErrorRate = 1;
+        for(uint32_t i = 0; i < n_cur; ++i)
+            if(cu[i].localErr < minimumErrorRate) minimumErrorRate = cu[i].localErr;
+        uint32_t w = 0;
+        for(uint32_t i = 0; i < n_cur; ++i) {
+            const double errorRateDiff = cu[i].localErr - minimumErrorRate;
+            if((errorRateDiff > 0.05 && currentLength > localK / 2) || (errorRateDiff > 0.1 && currentLength > 15)) {
+                free_leaf_slots(cu[i]);
+                continue;
+            }
+            if(w != i) cu[w] = cu[i];
+            ++w;
+        }
+        n_cur = w;
+        att_minErr = minimumErrorRate;
+        att_i = 0;
+        pc = PC_ATT_LEAF;
+    }
+    // first request of leaf att_i's getFMIndexExtensions (or the end of attempToExtend)
+    LRSC_SM void att_leaf()
+    {
+        if(att_i >= n_cur) { pc = PC_ATT_DONE; return; }
+        att_b = 0;
+        pc = PC_EXT;
+        ext_issue();
+    }
+    LRSC_SM void ext_issue()
+    {
+        const LeafT& lf = cur()[att_i];
+        const bool fv = lf.flo <= lf.fhi, rv = lf.rlo <= lf.rhi;
+        req_rank(lf.flo, lf.fhi, att_b, fv, lf.rlo, lf.rhi, 3u - att_b, rv, false);
+    }
+    LRSC_SM void ext_result(const SmReq<P>& res)
+    {
+        const uint32_t b = att_b;
+        // results land in statically indexed slots
+        if(b == 0) { ex_flo[0] = res.a_lo; ex_fhi[0] = res.a_hi; ex_rlo[0] = res.b_lo; ex_rhi[0] = res.b_hi; }
+        else if(b == 1) { ex_flo[1] = res.a_lo; ex_fhi[1] = res.a_hi; ex_rlo[1] = res.b_lo; ex_rhi[1] = res.b_hi; }
+        else if(b == 2) { ex_flo[2] = res.a_lo; ex_fhi[2] = res.a_hi; ex_rlo[2] = res.b_lo; ex_rhi[2] = res.b_hi; }
+        else { ex_flo[3] = res.a_lo; ex_fhi[3] = res.a_hi; ex_rlo[3] = res.b_lo; ex_rhi[3] = res.b_hi; }
+        ++att_b;
+        if(att_b < 4) { ext_issue(); return; }
+        // all four pairs known: the acceptance ladder, at most twice (second time with the threshold lowered by one,
+        // only for the best leaf of a multi-leaf frontier: .cpp:403-421)
+        LeafT* cu = cur();
+        const LeafT& par = cu[att_i];
+        int freq[4];
+        uint32_t mask = 0;
+        int count = 0;
+        while(count < 2) {
+            if(count == 1 && !(par.localErr == att_minErr && n_cur > 1)) break;
+            mask = ext_mask(par, freq);
+            if(mask != 0) break;
+            min_SA_threshold--;
+            count++;
+        }
+        min_SA_threshold += (uint64_t)count;
+        if(mask != 0) {
+            LeafT* nx = nxt();
+            for(uint32_t bb = 0; bb < 4; ++bb) {
+                if(!(mask & (1u << bb))) continue;
+                if(n_nxt >= kMaxChildren) { error = LRSC_WALK_ERR_CHILDREN; pc = PC_WALK_END; return; }
+                LeafT& ch = nx[n_nxt++];
+                ch = par;                                          // createChild copies the node state (SAINode.cpp:166-189)
+                ch.flo = ex_flo[bb]; ch.fhi = ex_fhi[bb]; ch.rlo = ex_rlo[bb]; ch.rhi = ex_rhi[bb];
+                ch.kmerFrequency = freq[bb];
+                ch.currOverlapLen++;
+                ch.queryOverlapLen++;
+                if(par.tailLetter == bb) ch.tailLetterCount = par.tailLetterCount + 1;
+                else { ch.tailLetter = bb; ch.tailLetterCount = 1; }
+                suf_push(ch, bb);
+                ch.parent = (uint16_t)att_i;
+                ch.ext = (uint8_t)bb;
+                ch.alive = 1;
+            }
+        }
+        ++att_i;
+        pc = att_i >= n_cur ? PC_ATT_DONE : PC_ATT_LEAF;          // ATT_DONE's block comes later in this same sweep
+    }
+
+    // extendLeaves' control flow after an attempToExtend (.cpp:239-278)
+    LRSC_SM void att_done()
+    {
+        if(n_nxt == 0) {
+            if(att_no == 1) {                                   // level 1: reduce the k-mer size
+                const uint64_t LowerBound = (currentKmerSize - 2) > minOverlap() ? (currentKmerSize - 2) : minOverlap();
+                sf_begin(0, n_cur, LowerBound, currentKmerSize, PC_AFTER_SF_A);
+                return;
+            }
+            if(att_no == 2) {                                   // level 2: reduce the threshold
+                min_SA_threshold--;
+                att_no = 3;
+                pc = PC_ATT_ENTRY;
+                return;
+            }
+        }
+        if(att_no == 3) min_SA_threshold++;
+        pc = PC_POST;
+    }
+    LRSC_SM void post()
+    {
+        if(n_nxt != 0) {
+            currentLength++;
+            currentKmerSize++;
+            if(isInsufficientFreqs(nxt(), n_nxt)) {
+                const uint64_t LowerBound = (currentKmerSize - 2) > minOverlap() ? (currentKmerSize - 2) : minOverlap();
+                sf_begin(1, n_nxt, LowerBound, currentKmerSize, PC_AFTER_SF_B);
+                return;
+            }
+        }
+        pc = PC_PRUNE;
+    }
+
+    // PrunedBySeedSupport + the rest of one extendOverlap iteration (.cpp:155-211)
+    LRSC_SM void prune_and_commit()
+    {
+        PrunedBySeedSupport();
+        LeafT* nx = nxt(); LeafT* cu = cur();
+        const uint32_t pathw = rw.pathw;
+        uint32_t survivors = 0;
+        for(uint32_t c = 0; c < n_nxt; ++c) survivors += nx[c].alive;
+        ++steps;
+        if(survivors > A->max_leaves) {
+            if(currentLength >= minLength)
+                for(uint32_t c = 0; c < n_nxt; ++c) {
+                    if(!nx[c].alive) continue;
+                    const LeafT& par = cu[nx[c].parent];
+                    terminated_leaf(nx[c], paths() + (uint64_t)par.path * pathw, par.path_len, (int)nx[c].ext);
+                    if(error) { pc = PC_WALK_END; return; }
+                }
+            n_cur = survivors;
+            ended = true;
+            pc = PC_STEP_ENTRY;
+            return;
+        }
+        uint32_t has_child = 0;
+        for(uint32_t c = 0; c < n_nxt; ++c) if(nx[c].alive) has_child |= 1u << nx[c].parent;
+        for(uint32_t i = 0; i < n_cur; ++i) if(!((has_child >> i) & 1u)) free_leaf_slots(cu[i]);
+        // copies first (they read the parent's buffers before the in-place child appends to them)
+        uint32_t seen = 0;
+        for(uint32_t c = 0; c < n_nxt; ++c) {
+            LeafT& ch = nx[c];
+            if(!ch.alive) continue;
+            const LeafT& par = cu[ch.parent];
+            if(!((seen >> ch.parent) & 1u)) { seen |= 1u << ch.parent; ch.ring = par.ring; ch.path = par.path; continue; }
+            const uint32_t s = alloc_slot();
+            ch.ring = (uint16_t)s; ch.path = (uint16_t)s;
+            const double* src = rings() + (uint64_t)par.ring * 100;
+            double* dst = rings() + (uint64_t)ch.ring * 100;
+            for(uint32_t kk = 0; kk < 100; ++kk) dst[kk] = src[kk];
+            const uint32_t* ps = paths() + (uint64_t)par.path * pathw;
+            uint32_t* pd = paths() + (uint64_t)ch.path * pathw;
+            const uint32_t nw = (par.path_len + 16) >> 4;
+            for(uint32_t kk = 0; kk < nw; ++kk) pd[kk] = ps[kk];
+        }
+        uint32_t w = 0;
+        for(uint32_t c = 0; c < n_nxt; ++c) {
+            LeafT& ch = nx[c];
+            if(!ch.alive) continue;
+            rings()[(uint64_t)ch.ring * 100 + (ch.hist_size - 1) % 100] = ch.globalErr;     // GlobalErrorRateRecord.push_back
+            path_set(paths() + (uint64_t)ch.path * pathw, ch.path_len, ch.ext);
+            ch.path_len++;
+            cu[w++] = ch;                                          // m_leaves = newLeaves (w <= 32 here)
+        }
+        n_cur = w;
+        if(currentLength >= minLength)
+            for(uint32_t i = 0; i < n_cur; ++i) {
+                terminated_leaf(cu[i], paths() + (uint64_t)cu[i].path * pathw, cu[i].path_len, -1);
+                if(error) { pc = PC_WALK_END; return; }
+            }
+        pc = PC_STEP_ENTRY;
+    }
+
+    // loop condition of extendOverlap + the head of extendLeaves
+    LRSC_SM void step_entry()
+    {
+        if(ended || error || !(n_cur != 0 && n_cur <= A->max_leaves && currentLength <= maxLength)) { pc = PC_WALK_END; return; }
+        n_nxt = 0;
+        att_no = 1;
+        if(currentKmerSize > maxOverlap) { fs_begin(0, n_cur, maxOverlap, PC_ATT_ENTRY, true); return; }
+        pc = PC_ATT_ENTRY;
+    }
+
+    LRSC_SM int finish_walk(uint32_t* out_len_, uint32_t* out_words, uint32_t* out_match_i)      // findTheBestPath (.cpp:214-236)
+    {
+        if(error) return error;
+        if(n_results > 0) {
+            const WalkResultRec* rs = results();
+            double minErrorRate = 1;
+            int bestI = -1;
+            for(uint32_t i = 0; i < n_results; ++i)
+                if(rs[i].error_rate < minErrorRate) { minErrorRate = rs[i].error_rate; bestI = (int)i; }
+            if(bestI < 0) return -4;
+            *out_len_ = rs[bestI].path_len;
+            *out_match_i = rs[bestI].match_i;
+            const uint32_t* src = rpaths() + (uint64_t)bestI * rw.pathw;
+            const uint32_t nw = (rs[bestI].path_len + 15) >> 4;
+            for(uint32_t kk = 0; kk < nw; ++kk) out_words[kk] = src[kk];
+            return 1;
+        }
+        if(n_cur == 0) return -1;
+        else if(currentLength > maxLength) return -2;
+        else if(n_cur > A->max_leaves) return -3;
+        return -4;
+    }
+
+    // =========================================================================================================
+    // PREP: the constructor's per-offset searches (.cpp:82-94,127-152): bi-intervals of the 5-mer, the idmer and,
+    // inside the target seed, the minOverlap-mer starting at every offset of m_query
+    // =========================================================================================================
+    LRSC_SM void prep_emit()
+    {
+        const uint32_t i = prep_i, s = prep_s;
+        const bool fval = prep_flo <= prep_fhi, rval = prep_rlo <= prep_rhi;
+        if(s == 5) flags5()[i] = (uint8_t)((fval ? 1 : 0) | (rval ? 2 : 0));
+        if(s == seedSize()) {
+            SortItem* a = it9f() + i; SortItem* b = it9r() + i;
+            a->key = fval ? (uint64_t)prep_flo : kNoKey; a->val = i; a->pad = 0;
+            b->key = rval ? (uint64_t)prep_rlo : kNoKey; b->val = i; b->pad = 0;
+        }
+        if(s == minOverlap() && prep_term) {
+            P* t = term() + (uint64_t)(i - (uint32_t)(k + interval)) * 4;
+            t[0] = prep_flo; t[1] = prep_fhi; t[2] = prep_rlo; t[3] = prep_rhi;
+        }
+    }
+    LRSC_SM void prep_advance()
+    {
+        const uint32_t seedk = seedSize(), mink = minOverlap();
+        const uint8_t* qq = q();
+        const uint32_t trg0 = (uint32_t)(k + interval);
+        while(true) {
+            if(prep_start) {
+                if(prep_i >= Lq) { pc = PC_BEGIN; return; }
+                const uint32_t i = prep_i;
+                prep_term = i >= trg0 && i + mink <= Lq;
+                uint32_t kmax = 0;
+                if(i + 5 <= Lq) kmax = 5;
+                if(i + seedk <= Lq) kmax = seedk;
+                if(prep_term) kmax = mink > kmax ? mink : kmax;
+                prep_kmax = kmax;
+                prep_s = 0; prep_fb = false; prep_rb = false;
+                prep_flo = prep_fhi = prep_rlo = prep_rhi = 0;
+                prep_start = false;
+            }
+            if(prep_s >= prep_kmax) { ++prep_i; prep_start = true; continue; }
+            const uint32_t s = prep_s;
+            const uint32_t next_emit = s < 5 ? 5u : s < seedk ? seedk : mink;
+            if(next_emit <= prep_kmax) {
+                const int tb = best_table(next_emit);
+                if(tb >= 0 && table_k(tb) == next_emit) {
+                    uint32_t code = 0;
+                    for(uint32_t t = 0; t < next_emit; ++t) code = (code << 2) | qq[prep_i + t];
+                    prep_s = next_emit | 0x80000000u;
+                    req_tab((uint32_t)tb, code);
+                    return;
+                }
+            }
+            const uint32_t c = qq[prep_i + s];
+            if(s == 0) {
+                const IvT<P> f = init_interval<P>(sF, c), rr = init_interval<P>(sR, 3u - c);
+                prep_flo = f.lo; prep_fhi = f.hi; prep_rlo = rr.lo; prep_rhi = rr.hi;
+                prep_s = 1;
+                n_rank += 2;
+                prep_emit();
+                continue;
+            }
+            if(prep_fb && prep_rb) { ++prep_s; prep_emit(); continue; }     // both strands dead: nothing can change any more
+            req_rank(prep_flo, prep_fhi, c, !prep_fb, prep_rlo, prep_rhi, 3u - c, !prep_rb, false);
+            return;
+        }
+    }
+    LRSC_SM void prep_result(const SmReq<P>& res)
+    {
+        if(prep_s & 0x80000000u) {
+            prep_s &= 0x7FFFFFFFu;
+            prep_flo = res.a_lo; prep_fhi = res.a_hi; prep_rlo = res.b_lo; prep_rhi = res.b_hi;
+            prep_fb = prep_flo > prep_fhi; prep_rb = prep_rlo > prep_rhi;
+        } else {
+            if(!prep_fb) { prep_flo = res.a_lo; prep_fhi = res.a_hi; prep_fb = prep_flo > prep_fhi; }
+            if(!prep_rb) { prep_rlo = res.b_lo; prep_rhi = res.b_hi; prep_rb = prep_rlo > prep_rhi; }
+            ++prep_s;
+        }
+        prep_emit();
+        prep_advance();
+    }
+
+    // =========================================================================================================
+    // the chain: PacBioSelfCorrectionProcess::initCorrect (:56-157) / correctByFMExtension (:159-206)
+    // =========================================================================================================
+    LRSC_SM void load_source(const int32_t* T0)
+    {
+        S_end = T0[0] + T0[1] - 1; S_endBest = T0[5]; S_isRepeat = (T0[3] & 1) != 0; S_maxFixed = T0[2];
+    }
+
+    // set up at kernel start (fresh read, or a read that yielded / was parked in an earlier launch)
+    LRSC_SM void init(const FmIndexDev* fm_, const CorrectArgs* a_, uint32_t read_index)
+    {
+        fm = fm_; A = a_; r = read_index;
+        sF = strand_consts<P>(fm->strand[LRSC_RBWT]);
+        sR = strand_consts<P>(fm->strand[LRSC_BWT]);
+        rw = A->work[r];
+        ReadOut& R = A->out[r];
+        const uint64_t rs = A->read_off[r];
+        rlen = (uint32_t)(A->read_off[r + 1] - rs);
+        read = A->codes + rs;
+        n_seeds = A->seed_count[r];
+        seeds = A->seeds + seed_slab(rs, r, A->min_k) * kSeedInts;
+        out = A->out_codes + rw.out_off;
+        piece_start = A->piece_start + rw.piece_off;
+        ws = A->workspace + rw.ws_off;
+        req.kind = kReqNone;
+        n_rank = 0; n_blk = 0; n_tab = 0;
+        error = 0; state = kReadDone; walks_here = 0; next = 0; firstType = 0;
+        correctedLen = 0; totalWalkNum = 0; highErrorNum = 0; exceedDepthNum = 0; exceedLeaveNum = 0; FMNum = 0; DPNum = 0; seedDis = 0;
+        out_len = 0; n_pieces = 0; steps = 0;
+        S_seedLen = 0; S_end = 0; S_endBest = 0; S_maxFixed = 0; S_isRepeat = false; it = 1;
+        const bool resume = A->resume != 0;
+        if(resume) {
+            correctedLen = R.c[1]; totalWalkNum = R.c[3]; highErrorNum = R.c[4]; exceedDepthNum = R.c[5]; exceedLeaveNum = R.c[6];
+            FMNum = R.c[7]; DPNum = R.c[8]; seedDis = R.c[9];
+            out_len = R.out_len; n_pieces = R.n_pieces; steps = R.steps;
+        } else { R.cyc[0] = 0; R.cyc[1] = 0; R.cyc[2] = 0; R.cyc[3] = 0; R.steps = 0; }
+        steps0 = steps;
+        if(!(n_seeds >= 2) || (resume && R.state == kReadDone)) { pc = PC_FINAL; return; }
+        if(!resume) {
+            // pieceVec.push_back(seedVec[0])
+            piece_start[n_pieces++] = 0;
+            for(int t = 0; t < seeds[1]; ++t) out[out_len++] = read[seeds[0] + t];
+            S_seedLen = seeds[1];
+            load_source(seeds);
+            it = 1;
+        } else {
+            S_seedLen = R.s_seed_len; S_end = R.s_end; S_endBest = R.s_end_best; S_maxFixed = R.s_max_fixed; S_isRepeat = R.s_is_repeat != 0;
+            it = R.it;
+            if(R.state == kReadParked) {
+                // correctByMSAlignment's tail (:237-244) with the DP stage's answer for target = *iterTarget
+                const uint32_t di = A->dp_index[r];
+                const DpMsaOut m = A->dp_msa[di];
+                const int32_t* T0 = seeds + (uint64_t)it * kSeedInts;
+                if(m.error) error = LRSC_WALK_ERR_DP;
+                else if(m.n_rows > 3) {
+                    const uint8_t* cons = A->dp_cons + A->dp_reqs[di].cons_off;
+                    if(m.cons_len < R.dp_k) error = LRSC_WALK_ERR_DP;              // out.erase(0, k) would throw in the reference
+                    else {
+                        const uint32_t appended = m.cons_len - R.dp_k;
+                        if(out_len + appended > rw.out_cap) error = LRSC_WALK_ERR_OUTPUT;
+                        else {
+                            for(uint32_t j = 0; j < appended; ++j) out[out_len + j] = cons[R.dp_k + j];
+                            out_len += appended;
+                            correctedLen += appended;
+                            seedDis += T0[0] - S_end - 1;
+                            DPNum++;
+                            S_seedLen += (int)appended;
+                        }
+                    }
+                } else if(A->split) {
+                    if(out_len + (uint32_t)T0[1] > rw.out_cap) error = LRSC_WALK_ERR_OUTPUT;
+                    else {
+                        piece_start[n_pieces++] = out_len;
+                        for(int t = 0; t < T0[1]; ++t) out[out_len++] = read[T0[0] + t];
+                        S_seedLen = T0[1];
+                        correctedLen += T0[1];
+                    }
+                } else {
+                    const int raw = (T0[0] + T0[1] - 1) - S_end;
+                    if(out_len + (uint32_t)raw > rw.out_cap) error = LRSC_WALK_ERR_OUTPUT;
+                    else {
+                        for(int t = 0; t < raw; ++t) out[out_len++] = read[S_end + 1 + t];
+                        S_seedLen += raw;
+                        correctedLen += T0[1];
+                    }
+                }
+                load_source(T0);
+                it += 1;
+            }
+        }
+        pc = PC_NEXT;
+    }
+
+    // true while the lane waits for its wavefront's set-up quorum
+    LRSC_SM bool wants_setup() const { return pc == PC_NEXT; }
+
+    // between walks: end of the chain, budget, or the next walk's geometry + m_query (:163-184)
+    LRSC_SM void next_walk(bool setup_now)
+    {
+        if(!(it < n_seeds) || error) { pc = PC_FINAL; return; }
+        if(next == 0 && A->max_walks != 0 && (walks_here >= A->max_walks || steps - steps0 >= (uint64_t)A->max_steps)) {
+            state = kReadYield; pc = PC_FINAL; return;
+        }
+        if(!setup_now) return;
+        ++walks_here;
+        const int32_t* T = seeds + (uint64_t)(it + (uint32_t)next) * kSeedInts;
+        T_start = T[0]; T_len = T[1];
+        T_isRepeat = (T[3] & 1) != 0;
+        interval = T_start - S_end - 1;
+        k = (S_endBest < T[4] ? S_endBest : T[4]) - 2;                     // min(source.endBest, target.startBest) - 2
+        if(S_isRepeat || T_isRepeat) {
+            k = S_seedLen < T_len ? S_seedLen : T_len;
+            k = k < A->start_kmer_len + 2 ? k : A->start_kmer_len + 2;
+        }
+        rtou = S_isRepeat && !T_isRepeat;
+        trg_len = rtou ? k : T_len;
+        if(k < (int)A->seed_size || k > (int)kMaxInitK || k > S_seedLen || interval < 0 || trg_len < (int)A->min_overlap ||
+           (uint32_t)(k + interval + trg_len) > rw.lq_max) { error = LRSC_WALK_ERR_GEOMETRY; pc = PC_FINAL; return; }
+        Lq = (uint32_t)(k + interval + trg_len);
+        uint8_t* qq = q();
+        const uint8_t* tail = out + out_len - k;                           // source.seedStr.substr(seedLen - k)
+        if(!rtou) {
+            for(int t = 0; t < k; ++t) qq[t] = tail[t];
+            for(int t = 0; t < interval; ++t) qq[k + t] = read[S_end + 1 + t];
+            for(int t = 0; t < T_len; ++t) qq[k + interval + t] = read[T_start + t];
+        } else {
+            // src <-> trg swapped and everything reverse-complemented (:176-184)
+            for(int t = 0; t < k; ++t) qq[t] = (uint8_t)(3 - read[T_start + k - 1 - t]);
+            for(int t = 0; t < interval; ++t) qq[k + t] = (uint8_t)(3 - read[S_end + interval - t]);
+            for(int t = 0; t < k; ++t) qq[k + interval + t] = (uint8_t)(3 - tail[k - 1 - t]);
+        }
+        initk = (uint32_t)k;
+        maxOverlap = (uint32_t)k + 2;
+        const int min_SA = A->pb_coverage > 60 ? (int)((A->pb_coverage / 60) * 3) : 3;
+        min_SA_threshold = (uint64_t)min_SA;
+        if(interval > 100) maxIndelSize = (uint64_t)(interval * 0.2); else maxIndelSize = 20;
+        maxLength = (uint64_t)((1.2 * (interval + 10)) + (double)(2 * (uint64_t)k));
+        minLength = (uint64_t)((0.8 * (interval - 20)) + (double)(2 * (uint64_t)k));
+        prep_i = 0; prep_start = true;
+        pc = PC_PREP;
+    }
+
+    // the walk is over: stitch its result or fall back (:185-206, :119-149)
+    LRSC_SM void walk_end()
+    {
+        uint32_t plen = 0, mi = 0;
+        uint32_t* bestw = best();
+        const int code = finish_walk(&plen, bestw, &mi);
+        if(code <= LRSC_WALK_ERR_CHILDREN) { error = code; pc = PC_FINAL; return; }
+        if(next == 0) firstType = code;
+        const int32_t* T = seeds + (uint64_t)(it + (uint32_t)next) * kSeedInts;
+        const uint8_t* qq = q();
+        if(code > 0) {
+            // merged = path + target.substr(i + minOverlap); out = merged (un-reversed) minus its first k characters
+            const uint32_t tail_from = mi + A->min_overlap;
+            const uint32_t tlen = (uint32_t)trg_len - tail_from;
+            const uint32_t M = plen + tlen;
+            uint32_t appended = 0;
+            if(!rtou) {
+                appended = M - (uint32_t)k;
+                if(out_len + appended > rw.out_cap) { error = LRSC_WALK_ERR_OUTPUT; pc = PC_FINAL; return; }
+                for(uint32_t j = (uint32_t)k; j < M; ++j)
+                    out[out_len + j - k] = (uint8_t)(j < plen ? path_get(bestw, j) : qq[k + interval + tail_from + (j - plen)]);
+            } else {
+                // revcomp(merged) + target.substr(k), minus the first k characters (:195-200)
+                const uint32_t total = M + (uint32_t)(T_len - k);
+                appended = total - (uint32_t)k;
+                if(out_len + appended > rw.out_cap) { error = LRSC_WALK_ERR_OUTPUT; pc = PC_FINAL; return; }
+                for(uint32_t j = (uint32_t)k; j < total; ++j) {
+                    uint8_t c;
+                    if(j < M) {
+                        const uint32_t m = M - 1 - j;
+                        c = (uint8_t)(3 - (m < plen ? path_get(bestw, m) : qq[k + interval + tail_from + (m - plen)]));
+                    } else
+                        c = read[T_start + k + (j - M)];
+                    out[out_len + j - k] = c;
+                }
+            }
+            out_len += appended;
+            correctedLen += appended;
+            seedDis += interval;
+            FMNum++;
+            totalWalkNum++;
+            S_seedLen += (int)appended;                                      // SeedFeature::append
+            S_end = T_start + T_len - 1; S_endBest = T[5]; S_isRepeat = T_isRepeat; S_maxFixed = T[2];
+            it += (uint32_t)next + 1;
+            next = 0;
+            pc = PC_NEXT;
+            return;
+        }
+        if(next + 1 < A->next_target && it + (uint32_t)next + 1 < n_seeds) { next++; pc = PC_NEXT; return; }
+        switch(firstType) {
+            case -1: highErrorNum++; break;
+            case -2: exceedDepthNum++; break;
+            case -3: exceedLeaveNum++; break;
+            default: error = LRSC_WALK_ERR_CODE; break;
+        }
+        if(error) { pc = PC_FINAL; return; }
+        totalWalkNum++;
+        const int32_t* T0 = seeds + (uint64_t)it * kSeedInts;               // target = *iterTarget
+        if(!A->no_dp) {
+            // correctByMSAlignment (:208-236): park the read with its query = src k-mer + raw segment + target seed
+            ReadOut& R = A->out[r];
+            const int iv0 = T0[0] - S_end - 1;
+            int k0 = (S_endBest < T0[4] ? S_endBest : T0[4]) - 2;
+            if(S_isRepeat || (T0[3] & 1)) {
+                k0 = S_seedLen < T0[1] ? S_seedLen : T0[1];
+                k0 = k0 < A->start_kmer_len + 2 ? k0 : A->start_kmer_len + 2;
+            }
+            if(k0 < 1 || k0 > S_seedLen || k0 > T0[1] || iv0 < 0 || (uint32_t)(k0 + iv0 + T0[1]) > rw.lq_max) { error = LRSC_WALK_ERR_GEOMETRY; pc = PC_FINAL; return; }
+            uint8_t* dq = dpq();
+            const uint8_t* tl = out + out_len - k0;
+            for(int t = 0; t < k0; ++t) dq[t] = tl[t];
+            for(int t = 0; t < iv0; ++t) dq[k0 + t] = read[S_end + 1 + t];
+            for(int t = 0; t < T0[1]; ++t) dq[k0 + iv0 + t] = read[T0[0] + t];
+            R.dp_k = (uint32_t)k0; R.dp_lq = (uint32_t)(k0 + iv0 + T0[1]);
+            R.dp_total_freq = (int64_t)S_maxFixed + (int64_t)T0[2];
+            state = kReadParked;
+            pc = PC_FINAL;
+            return;
+        }
+        if(A->split) {
+            if(out_len + (uint32_t)T0[1] > rw.out_cap) { error = LRSC_WALK_ERR_OUTPUT; pc = PC_FINAL; return; }
+            piece_start[n_pieces++] = out_len;                               // pieceVec.push_back(target)
+            for(int t = 0; t < T0[1]; ++t) out[out_len++] = read[T0[0] + t];
+            S_seedLen = T0[1];
+        } else {
+            const int raw = (T0[0] + T0[1] - 1) - S_end;                     // readSeq.substr(source.seedEndPos + 1, ...)
+            if(out_len + (uint32_t)raw > rw.out_cap) { error = LRSC_WALK_ERR_OUTPUT; pc = PC_FINAL; return; }
+            for(int t = 0; t < raw; ++t) out[out_len++] = read[S_end + 1 + t];
+            S_seedLen += raw;
+        }
+        correctedLen += T0[1];
+        load_source(T0);
+        it += 1;
+        next = 0;
+        pc = PC_NEXT;
+    }
+
+    LRSC_SM void finalize()
+    {
+        ReadOut& R = A->out[r];
+        R.steps = steps;
+        R.it = it; R.s_seed_len = S_seedLen; R.s_end = S_end; R.s_end_best = S_endBest; R.s_max_fixed = S_maxFixed;
+        R.s_is_repeat = S_isRepeat ? 1 : 0;
+        R.c[0] = rlen; R.c[1] = correctedLen; R.c[2] = n_seeds; R.c[3] = totalWalkNum; R.c[4] = highErrorNum;
+        R.c[5] = exceedDepthNum; R.c[6] = exceedLeaveNum; R.c[7] = FMNum; R.c[8] = DPNum; R.c[9] = seedDis;
+        R.n_pieces = n_pieces; R.out_len = out_len; R.merge = n_pieces != 0; R.error = error;
+        R.state = error ? kReadDone : state;
+        pc = PC_DONE;
+    }
+
+    // =========================================================================================================
+    // one sweep: consume the answered request (if any), then run forward through the blocks until the next request
+    // =========================================================================================================
+    LRSC_SM void sweep(bool have_result, const SmReq<P>& res, bool setup_now)
+    {
+        req.kind = kReqNone;
+        if(have_result) {
+            if(pc == PC_FS) fs_result(res);
+            else if(pc == PC_SF) sf_result_in(res);
+            else if(pc == PC_EXT) ext_result(res);
+            else if(pc == PC_PREP) prep_result(res);
+        }
+        if(pc == PC_ROOT_DONE) {
+            LeafT& root = cur()[0];
+            root.kmerFrequency = (int)(isize(root.flo, root.fhi) + isize(root.rlo, root.rhi));
+            pc = PC_STEP_ENTRY;
+        }
+        if(pc == PC_ATT_DONE) att_done();
+        if(pc == PC_AFTER_SF_A) { att_no = 2; fs_begin(0, n_cur, (uint32_t)sf_result, PC_ATT_ENTRY, true); }
+        if(pc == PC_POST) post();
+        if(pc == PC_AFTER_SF_B) fs_begin(1, n_nxt, (uint32_t)sf_result, PC_PRUNE, true);
+        if(pc == PC_PRUNE) prune_and_commit();
+        if(pc == PC_STEP_ENTRY) step_entry();
+        if(pc == PC_WALK_END) walk_end();
+        if(pc == PC_NEXT) next_walk(setup_now);
+        if(pc == PC_PREP && req.kind == kReqNone) prep_advance();
+        if(pc == PC_BEGIN) begin_walk();
+        if(pc == PC_ATT_ENTRY) att_entry();
+        if(pc == PC_ATT_LEAF) att_leaf();
+        if(pc == PC_FINAL) finalize();
+    }
+};
+
+} // namespace lrsc

@@ -46,7 +46,7 @@ uint64_t orc_bwt_num_strings(void* h) { return static_cast<RLBwt*>(h)->num_strin
 uint64_t orc_bwt_num_symbols(void* h) { return static_cast<RLBwt*>(h)->num_symbols(); }
 uint64_t orc_bwt_num_runs(void* h) { return static_cast<RLBwt*>(h)->num_runs(); }
 uint64_t orc_bwt_pc(void* h, char b) { return static_cast<RLBwt*>(h)->pc(bwt_rank_of(b)); }
-uint64_t orc_bwt_occ_calls(void* h) { return static_cast<RLBwt*>(h)->occ_calls; }
+uint64_t orc_bwt_occ_calls(void* h) { (void)h; return RLBwt::occ_calls_tls(); }
 void orc_bwt_occ_batch(void* h, const char* b, const int64_t* idx, uint64_t n, uint64_t* out)
 {
     const RLBwt* p = static_cast<RLBwt*>(h);

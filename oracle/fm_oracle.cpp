@@ -185,9 +185,15 @@ uint64_t RLBwt::nearest_marker_idx(uint64_t pos) const
     return (offset < (uint64_t)(kSmallRate >> 1)) ? base : base + 1;
 }
 
+uint64_t& RLBwt::occ_calls_tls()
+{
+    static thread_local uint64_t n = 0;
+    return n;
+}
+
 uint64_t RLBwt::occ(int rank, int64_t idx_signed) const
 {
-    ++occ_calls;
+    ++occ_calls_tls();
     uint64_t idx = (uint64_t)idx_signed;
     ++idx;                                           // marker counts are exclusive (RLBWT.h:125)
     const LargeMarker marker = interpolated_marker(nearest_marker_idx(idx));

@@ -80,8 +80,9 @@ public:
     // `count` (optional, int[4] indexed A,C,G,T) follows BWTAlgorithms.cpp:19 / .h:68
     Interval find_interval(const std::string& w, int* count = nullptr) const;
 
-    // counter of occ() calls (cpu-baseline accounting; not in the reference)
-    mutable uint64_t occ_calls = 0;
+    // counter of occ() calls made by the calling thread, summed over all RLBwt objects (cpu-baseline accounting; not in the
+    // reference).  Thread-local: bench.py's cpu_baseline runs one oracle thread per host core over a shared index.
+    static uint64_t& occ_calls_tls();
 
 private:
     void initialize_fm_index();                                          // RLBWT.cpp:109-248
