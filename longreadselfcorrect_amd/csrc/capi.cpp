@@ -1483,16 +1483,56 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
     a.profile = std::getenv("LRSC_CORRECT_PROFILE") ? 1u : 0u;
     a.setup_quorum_pct = 40;
     if(const char* e = std::getenv("LRSC_CORRECT_QUORUM")) a.setup_quorum_pct = (uint32_t)std::min(100, std::max(0, std::atoi(e)));
+    a.step_gate_pct = 75;
+    if(const char* e = std::getenv("LRSC_CORRECT_GATE")) a.step_gate_pct = (uint32_t)std::min(100, std::max(0, std::atoi(e)));
     a.max_walks = p.no_dp ? 0u : 64u;
     a.max_steps = 2000;
     if(const char* e = std::getenv("LRSC_CORRECT_MAX_WALKS")) a.max_walks = (uint32_t)std::max(0, std::atoi(e));
     if(const char* e = std::getenv("LRSC_CORRECT_MAX_STEPS")) a.max_steps = (uint32_t)std::max(1, std::atoi(e));
+    // LRSC_SM_TRACE=<file>: debugging aid, per-sweep trace of read LRSC_SM_TRACE_READ (first launch only)
+    DevBuf<uint32_t> d_trace;
+    const char* trace_file = std::getenv("LRSC_SM_TRACE");
+    if(trace_file && use_sm) {
+        a.trace_cap = 14u * 400000u + 1u;
+        HIP_TRY(d_trace.reserve(a.trace_cap));
+        HIP_TRY(hipMemset(d_trace.p, 0, (size_t)a.trace_cap * 4));
+        a.trace = d_trace.p;
+        a.trace_read = std::getenv("LRSC_SM_TRACE_READ") ? (uint32_t)std::atoi(std::getenv("LRSC_SM_TRACE_READ")) : 0u;
+    }
+    // LRSC_SM_PROFILE=1: per-wavefront tick totals of the state-machine kernel's sweep classes (first launch), on stderr
+    DevBuf<unsigned long long> d_prof;
+    uint32_t prof_waves = 0;
+    if(std::getenv("LRSC_SM_PROFILE") && use_sm) {
+        prof_waves = (n + a.reads_per_wave - 1) / a.reads_per_wave;
+        HIP_TRY(d_prof.reserve((size_t)prof_waves * 16));
+        HIP_TRY(hipMemset(d_prof.p, 0, (size_t)prof_waves * 16 * 8));
+        a.prof = d_prof.p;
+    }
     HIP_TRY(with_queue(a));
     int st = timed_launch(ctx, LRSC_K_EXTEND, [&]() { return launch_correct(a, ctx->stream); });
     if(st != LRSC_OK) return st;
 
     // ---- DP rounds: reads whose FM-extension failed are parked with a correctByMSAlignment request; the DP stage
     //      answers all of them at once and the kernel resumes just those reads (:129-149) -------------------------------
+    if(a.prof) {
+        std::vector<unsigned long long> pr((size_t)prof_waves * 16);
+        HIP_TRY(hipMemcpy(pr.data(), d_prof.p, pr.size() * 8, hipMemcpyDeviceToHost));
+        double tot[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for(uint32_t w = 0; w < prof_waves; ++w) for(int j = 0; j < 9; ++j) tot[j] += (double)pr[(size_t)w * 16 + j];
+        const double all = tot[0] + tot[1] + tot[2] + tot[3] + tot[4];
+        std::fprintf(stderr, "[lrsc] sm kernel, %u waves, ticks per wave %.3g: R-phase %.1f%%; sweeps: begin %.1f%% (%.0f sweeps/wave, %.0f ticks each), "
+                             "between-walks %.1f%% (%.0f, %.0f), step gate open %.1f%% (%.0f, %.0f), light %.1f%% (%.0f, %.0f)\n", prof_waves, all / prof_waves,
+                     100 * tot[0] / all, 100 * tot[1] / all, tot[5] / prof_waves, tot[1] / std::max(tot[5], 1.0), 100 * tot[2] / all, tot[6] / prof_waves,
+                     tot[2] / std::max(tot[6], 1.0), 100 * tot[3] / all, tot[7] / prof_waves, tot[3] / std::max(tot[7], 1.0), 100 * tot[4] / all,
+                     tot[8] / prof_waves, tot[4] / std::max(tot[8], 1.0));
+        a.prof = nullptr;
+    }
+    if(a.trace) {
+        std::vector<uint32_t> tr(a.trace_cap);
+        HIP_TRY(hipMemcpy(tr.data(), d_trace.p, (size_t)a.trace_cap * 4, hipMemcpyDeviceToHost));
+        if(std::FILE* f = std::fopen(trace_file, "wb")) { std::fwrite(tr.data(), 4, tr[0] ? tr[0] : 1, f); std::fclose(f); }
+        a.trace = nullptr;
+    }
     std::vector<ReadOut> ro(n);
     HIP_TRY(hipMemcpy(ro.data(), d_out.p, (size_t)n * sizeof(ReadOut), hipMemcpyDeviceToHost));
     if(!p.no_dp || a.max_walks != 0) {

@@ -68,6 +68,7 @@ struct CorrectArgs {
     uint32_t queue_waves;            // wavefronts to launch when the queue is used
     uint32_t profile;                // per-phase tick counters in ReadOut::cyc (LRSC_CORRECT_PROFILE)
     uint32_t setup_quorum_pct;       // lanes of a wavefront (in %) that must be between walks before they set the next ones up
+    uint32_t step_gate_pct;          // state-machine kernel: lanes inside a walk (in %) that must be at the step gate before it opens
     uint32_t max_steps;              // ... or extension steps: no new walk is started past this budget
     uint32_t max_walks;              // walks a read may run per launch before it yields (0 = no limit); keeps DP rounds even
     const uint32_t* dp_index;        // read -> request
@@ -78,6 +79,10 @@ struct CorrectArgs {
     double pacbio_error_rate;
     const double* freqs_of_kmer_size;
     DevCounters* ctr;
+    // debugging aid (LRSC_SM_TRACE): the state-machine kernel records (pc, request, answer) of read `trace_read` per sweep
+    unsigned long long* prof;        // LRSC_SM_PROFILE: 16 tick / count totals per wavefront (state-machine kernel)
+    uint32_t* trace;
+    uint32_t trace_cap, trace_read;
 };
 
 hipError_t launch_correct_plan(const CorrectArgs& a, hipStream_t stream);

@@ -5,6 +5,7 @@
 #include <cstring>
 
 #include "correct_dev.h"
+#include "ws_layout.h"
 #include "introsort_emul.h"
 
 namespace lrsc {
@@ -28,27 +29,14 @@ inline size_t layout_read_work(ReadWork& w, uint64_t rlen, uint32_t ns, const Re
     if(w.lq_max >= 65535) { *err = "walk: query longer than 65534 bases"; return 0; }
     const double maxLength = (1.2 * ((double)plan.gap_max + 10)) + (double)(2 * (uint64_t)kMaxInitK);
     w.pathw = (uint32_t)(((uint64_t)maxLength + 4 + 15) / 16 + 1);
-    const uint32_t lq = std::max<uint32_t>(w.lq_max, 16);
-    const uint32_t n9 = lq - idmer_len + 1, n5 = lq - 5 + 1;
-    const uint32_t nT = lq;                                       // >= |target| - minOverlap + 1
-    size_t o = 0;
-    w.o_item9f = (uint32_t)o; o += (size_t)n9 * sizeof(SortItem);
-    w.o_item9r = (uint32_t)o; o += (size_t)n9 * sizeof(SortItem);
-    w.o_term = (uint32_t)o;   o = layout_align_up(o + (size_t)nT * 4 * psz, 16);
-    w.o_leaves = (uint32_t)o; o = layout_align_up(o + (size_t)(32 + kMaxChildren) * lbytes, 16);
-    w.o_rings = (uint32_t)o;  o += (size_t)32 * 100 * sizeof(double);
-    w.o_results = (uint32_t)o; o += (size_t)kMaxResults * sizeof(WalkResultRec);
-    w.o_paths = (uint32_t)o;  o += (size_t)(32 + kMaxResults) * w.pathw * 4;
-    w.o_best = (uint32_t)o;   o += (size_t)w.pathw * 4;
-    w.o_next9f = (uint32_t)o; o += (size_t)n9 * 2;
-    w.o_next9r = (uint32_t)o; o += (size_t)n9 * 2;
-    w.o_head9 = (uint32_t)o;  o += 512 * 2;
-    w.o_head5 = (uint32_t)o;  o += 1024 * 2;
-    w.o_next5 = (uint32_t)o;  o += (size_t)n5 * 2;
-    w.o_flags5 = (uint32_t)o; o += n5;
-    w.o_query = (uint32_t)o;  o += lq;
-    w.o_dpq = (uint32_t)o;    o += lq;
-    o = layout_align_up(o, 64);
+    // fixed-size regions first (their offsets are compile-time constants for the state-machine kernel), then the ones that
+    // scale with the longest query / path of the read: ws_layout.h holds the one set of formulas both sides use
+    const WsVar v = ws_var_offsets((uint32_t)lbytes, (uint32_t)psz, w.lq_max, idmer_len, w.pathw);
+    w.o_leaves = ws_fixed_leaves(); w.o_rings = ws_fixed_rings((uint32_t)lbytes); w.o_results = ws_fixed_results((uint32_t)lbytes);
+    w.o_head9 = ws_fixed_head9((uint32_t)lbytes); w.o_head5 = ws_fixed_head5((uint32_t)lbytes);
+    w.o_item9f = v.item9f; w.o_item9r = v.item9r; w.o_term = v.term; w.o_paths = v.paths; w.o_best = v.best;
+    w.o_next9f = v.next9f; w.o_next9r = v.next9r; w.o_next5 = v.next5; w.o_flags5 = v.flags5; w.o_query = v.query; w.o_dpq = v.dpq;
+    size_t o = v.total;
     if(o >= (1ull << 32)) { *err = "read workspace too large"; return 0; }
     return o;
 }

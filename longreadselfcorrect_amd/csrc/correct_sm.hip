@@ -5,11 +5,13 @@
 // LongReadSelfCorrectByOverlap (PacBio/LongReadCorrectByOverlap.cpp:17-878).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "walk_sm.h"
 
 namespace lrsc {
 
-template <bool WIDE>
+template <bool WIDE, int EXMODE>
 __global__ __launch_bounds__(64, 2) void correct_sm_kernel(const FmIndexDev* __restrict__ fmp, const CorrectArgs* __restrict__ ap)
 {
     using P = typename Lay<WIDE>::pos_t;
@@ -19,29 +21,69 @@ __global__ __launch_bounds__(64, 2) void correct_sm_kernel(const FmIndexDev* __r
     const uint32_t stride = 64u / a.reads_per_wave;
     const uint32_t slot = blockIdx.x * a.reads_per_wave + threadIdx.x / stride;
     const bool owner = (threadIdx.x % stride) == 0 && slot < a.n_reads;
+    // the four extension pairs of a lane's getFMIndexExtensions wait here between R-phases (element-major: conflict-free)
+    __shared__ P ex_lds[16 * 64];
+    const StrandC<P> sF = strand_consts<P>(fmp->strand[LRSC_RBWT]);
+    const StrandC<P> sR = strand_consts<P>(fmp->strand[LRSC_BWT]);
     ReadSM<WIDE> L;
     L.pc = PC_DONE;
     L.req.kind = kReqNone;
     L.n_rank = 0; L.n_blk = 0; L.n_tab = 0;
-    if(owner) L.init(fmp, ap, a.order ? a.order[slot] : slot);
-    const StrandC<P> sF = strand_consts<P>(fmp->strand[LRSC_RBWT]);
-    const StrandC<P> sR = strand_consts<P>(fmp->strand[LRSC_BWT]);
-    const uint32_t quorum = a.setup_quorum_pct;
+    P ex_priv[16];
+    if(owner) {
+        if(EXMODE == 0) L.init(fmp, ap, &sF, &sR, a.order ? a.order[slot] : slot, ex_lds + threadIdx.x, 64);
+        else            L.init(fmp, ap, &sF, &sR, a.order ? a.order[slot] : slot, ex_priv, 1);
+    }
+    const uint32_t quorum = a.setup_quorum_pct, gate_pct = a.step_gate_pct;
+    P* const ex = EXMODE == 0 ? ex_lds + threadIdx.x : ex_priv;
+    const uint32_t ex_stride = EXMODE == 0 ? 64u : 1u;
+    uint32_t trace_pos = 1;
+    unsigned long long* const prof = a.prof;
+    uint64_t p_r = 0, p_cls[4] = {0, 0, 0, 0}, p_n[4] = {0, 0, 0, 0};
     SmReq<P> res;
     res.a_lo = res.a_hi = res.b_lo = res.b_hi = 0;
     while(true) {
         const bool live = L.pc != PC_DONE;
         const unsigned long long live_mask = __ballot(live);
         if(live_mask == 0) break;
-        // setting up a walk (interval trees, root) is a long lane-serial stretch: lanes between walks wait until a quorum
-        // of the wavefront's live lanes is between walks, then set up together
+        // Three wave-level gates keep the long, memory-latency-bound blocks of the sweep from running for one lane at a time:
+        //  * set-up: lanes between walks wait until a quorum of the live lanes is between walks, then build their queries and
+        //    start PREP together;
+        //  * begin: the chain construction (sort) + root start when no lane is in PREP any more;
+        //  * step: lanes whose extension request is answered (and lanes ready to prune) wait until a quorum of the lanes that
+        //    are inside a walk has arrived, then run the acceptance ladder / children / pruning / commit in the same sweep.
         const uint32_t n_all = (uint32_t)__builtin_popcountll(live_mask);
         const uint32_t n_need = (uint32_t)__builtin_popcountll(__ballot(live && L.wants_setup()));
         const bool setup_now = n_need * 100u >= n_all * quorum;
+        const bool begin_now = __ballot(live && L.in_prep()) == 0;
+        const uint32_t n_walk = (uint32_t)__builtin_popcountll(__ballot(live && L.in_walk()));
+        const uint32_t n_gate = (uint32_t)__builtin_popcountll(__ballot(live && L.at_gate()));
+        const bool gate_now = n_gate * 100u >= n_walk * gate_pct;
         const bool have = L.req.kind != kReqNone;
-        if(have) sm_answer<WIDE>(*fmp, sF, sR, mtab, L.req, res, L.n_rank, L.n_blk, L.n_tab);
-        if(live) L.sweep(have, res, setup_now);
+        // profiling classes of this sweep (wave-uniform): 0 begin (sort + root), 1 between walks (stitch / next query), 2 step gate
+        // open, 3 light (searches only)
+        uint32_t cls = 3;
+        if(prof) {
+            const bool any_begin = begin_now && __ballot(live && L.pc == PC_BEGIN) != 0;
+            const bool any_next = __ballot(live && (L.pc == PC_WALK_END || (L.pc == PC_NEXT && setup_now))) != 0;
+            cls = any_begin ? 0u : any_next ? 1u : (gate_now && n_gate != 0) ? 2u : 3u;
+        }
+        const uint64_t t0 = prof ? __builtin_readcyclecounter() : 0;
+        if(have) sm_answer<WIDE>(*fmp, sF, sR, mtab, L.req, res, ex, ex_stride, L.n_rank, L.n_blk, L.n_tab);
+        const uint64_t t1 = prof ? __builtin_readcyclecounter() : 0;
+        if(a.trace != nullptr && live && L.r == a.trace_read) sm_trace<P>(a.trace, a.trace_cap, trace_pos, L.pc, have, L.req, res);
+        if(live) L.sweep(have, res, setup_now, begin_now, gate_now);
+        if(prof) {
+            const uint64_t t2 = __builtin_readcyclecounter();
+            p_r += t1 - t0;
+            p_cls[cls] += t2 - t1; p_n[cls] += 1;
+        }
     }
+    if(prof && threadIdx.x == 0) {
+        unsigned long long* o = prof + (size_t)blockIdx.x * 16;
+        o[0] = p_r; for(int c = 0; c < 4; ++c) { o[1 + c] = p_cls[c]; o[5 + c] = p_n[c]; }
+    }
+    if(a.trace != nullptr && owner && L.r == a.trace_read) a.trace[0] = trace_pos;
     flush_counters(a.ctr, L.n_rank, L.n_blk, L.n_tab);
 }
 
@@ -50,8 +92,14 @@ hipError_t launch_correct_sm(const FmIndexDev* d_fm, const CorrectArgs* d_args, 
     if(a.n_reads == 0) return hipSuccess;
     if(a.reads_per_wave == 0 || a.reads_per_wave > 64 || (a.reads_per_wave & (a.reads_per_wave - 1))) return hipErrorInvalidValue;
     const unsigned nb = (a.n_reads + a.reads_per_wave - 1) / a.reads_per_wave;
-    if(wide) hipLaunchKernelGGL(correct_sm_kernel<true>, dim3(nb), dim3(64), 0, stream, d_fm, d_args);
-    else     hipLaunchKernelGGL(correct_sm_kernel<false>, dim3(nb), dim3(64), 0, stream, d_fm, d_args);
+    const bool priv = std::getenv("LRSC_SM_EX") != nullptr;
+    if(priv) {
+        if(wide) hipLaunchKernelGGL((correct_sm_kernel<true, 1>), dim3(nb), dim3(64), 0, stream, d_fm, d_args);
+        else     hipLaunchKernelGGL((correct_sm_kernel<false, 1>), dim3(nb), dim3(64), 0, stream, d_fm, d_args);
+    } else {
+        if(wide) hipLaunchKernelGGL((correct_sm_kernel<true, 0>), dim3(nb), dim3(64), 0, stream, d_fm, d_args);
+        else     hipLaunchKernelGGL((correct_sm_kernel<false, 0>), dim3(nb), dim3(64), 0, stream, d_fm, d_args);
+    }
     return hipGetLastError();
 }
 

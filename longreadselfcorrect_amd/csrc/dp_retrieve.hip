@@ -3,11 +3,16 @@
 //   dp_seed_kernel      lane per (request, direction): bi-interval of the source k-mer (query[0..k)) and of the
 //                       reverse-complemented target k-mer (revcomp(query[Lq-k..))): fwd = reverse(w) in the rBWT,
 //                       rvc = revcomp(w) in the BWT, each with findInterval's early exit (:681-682).
-//                       Built without optimisation on purpose: at -O3 this kernel (per-lane k and a per-lane
-//                       choice of forward / reverse-complemented characters around the shared walk_step) came out
-//                       with wrong rBWT intervals for 'T' steps on ROCm 7.2 / gfx950 while the identical source at
-//                       -O0 and lrsc_find_kmers at -O3 are right; it does two 13-step walks per request, so its speed
-//                       is irrelevant.  tests/test_gpu_fm.py::test_dp_consensus_matches_oracle pins the counts.
+//                       Round 1 built this kernel `optnone`.  Root cause, pinned on the GPU in round 2 with five source
+//                       variants of this loop (tools/dp_seed_variants.py, profiles/r02_dp_seed_variants.txt): with
+//                       `uint32_t c = q[..]; if(dir != 0) c = 3u - c;` -- a per-lane select between a zero-extended byte
+//                       and 3 minus it, so that the compiler only knows c in [-252, 255] -- ROCm 7.2 -O3 emits wrong
+//                       intervals for 27-29 of 60 requests (per-lane k or not, early break or not, with or without a
+//                       compiler barrier per step: all fail); the same loop with the character formed as
+//                       `(q[..] ^ (dir ? 3 : 0)) & 3` (range [0, 3] visible) matches the oracle 60 / 60 at -O3.  The shared
+//                       walk_step / update_interval code is unchanged and every other kernel feeds it characters straight
+//                       from byte loads; this kernel now uses the xor form and is built -O3 like the rest.
+//                       tests/test_gpu_fm.py::test_dp_consensus_matches_oracle (per-lane k in {13,15,17,19}) pins it.
 //   dp_retrieve_kernel  lane per retrieved string: starts at one row of such an interval (at most `coverage` rows
 //                       per interval, :685-687,:704-706) and LF-walks up to maxLength - k characters, stopping at '$'.
 //                       The string is written in the orientation retrieveMatches aligns (:697-700,:716-719):
@@ -17,19 +22,17 @@
 //                       the slot end) together with the DpJob the alignment kernel consumes.
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
-
 #include "dp_dev.h"
 #include "rank_device.h"
 
 namespace lrsc {
 
-// body shared by the variants below.  V: 0/1 = as written, 2 = character via xor + mask (range known to the compiler),
-// 3 = wave-uniform trip count + per-lane predicate, 4 = no early break, 5 = compiler barrier per step
-template <bool WIDE, int V>
-__device__ __forceinline__ void dp_seed_body(const FmIndexDev& fm, const DpPipeArgs& a, const uint32_t* mtab)
+template <bool WIDE>
+__global__ __launch_bounds__(256) void dp_seed_kernel(FmIndexDev fm, DpPipeArgs a)
 {
     using P = typename Lay<WIDE>::pos_t;
+    __shared__ __attribute__((aligned(16))) uint32_t mtab[MaskTabSize<WIDE>::value];
+    init_mask_table<WIDE>(mtab);
     const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     uint32_t n_rank = 0, n_blk = 0;
     if(gid < (uint64_t)a.n_reqs * 2) {
@@ -40,27 +43,11 @@ __device__ __forceinline__ void dp_seed_body(const FmIndexDev& fm, const DpPipeA
         const StrandC<P> sf = strand_consts<P>(fm.strand[LRSC_RBWT]);
         const StrandC<P> sr = strand_consts<P>(fm.strand[LRSC_BWT]);
         WalkState<P> st = walk_init<P>();
-        if(V == 3) {
-            uint32_t kmax = k;
-            for(int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)kmax, o, 64); kmax = t > kmax ? t : kmax; }
-            kmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)kmax);
-            for(uint32_t s = 0; s < kmax; ++s) {
-                if(s < k && !(st.fwd_broken && st.rvc_broken)) {
-                    uint32_t c = q[dir == 0 ? s : lq - 1 - s];
-                    if(dir != 0) c = 3u - c;
-                    st = walk_step<WIDE>(sf, sr, c, k, st, mtab);
-                }
-            }
-        } else {
-            for(uint32_t s = 0; s < k; ++s) {
-                if(V != 4 && st.fwd_broken && st.rvc_broken) break;
-                uint32_t c;
-                if(V == 2) c = ((uint32_t)q[dir == 0 ? s : lq - 1 - s] ^ (dir != 0 ? 3u : 0u)) & 3u;
-                else { c = q[dir == 0 ? s : lq - 1 - s]; if(dir != 0) c = 3u - c; }
-                if(V == 4) { if(!(st.fwd_broken && st.rvc_broken)) st = walk_step<WIDE>(sf, sr, c, k, st, mtab); }
-                else st = walk_step<WIDE>(sf, sr, c, k, st, mtab);
-                if(V == 5) asm volatile("" ::: "memory");
-            }
+        for(uint32_t s = 0; s < k; ++s) {
+            if(st.fwd_broken && st.rvc_broken) break;
+            // complement as xor + mask, NOT `c = q[..]; if(dir) c = 3u - c;`: see the note in the file header
+            const uint32_t c = ((uint32_t)q[dir == 0 ? s : lq - 1 - s] ^ (dir != 0 ? 3u : 0u)) & 3u;
+            st = walk_step<WIDE>(sf, sr, c, k, st, mtab);
         }
         const bool fv = st.fwd.lo <= st.fwd.hi, rv = st.rvc.lo <= st.rvc.hi;
         const uint64_t nf = fv ? (uint64_t)(st.fwd.hi - st.fwd.lo) + 1 : 0, nr = rv ? (uint64_t)(st.rvc.hi - st.rvc.lo) + 1 : 0;
@@ -69,21 +56,6 @@ __device__ __forceinline__ void dp_seed_body(const FmIndexDev& fm, const DpPipeA
         n_rank = st.n_rank; n_blk = st.n_blk;
     }
     flush_counters(a.ctr, n_rank, n_blk);
-}
-
-template <bool WIDE>
-__global__ __launch_bounds__(256) __attribute__((optnone)) void dp_seed_kernel(FmIndexDev fm, DpPipeArgs a)
-{
-    __shared__ __attribute__((aligned(16))) uint32_t mtab[MaskTabSize<WIDE>::value];
-    init_mask_table<WIDE>(mtab);
-    dp_seed_body<WIDE, 0>(fm, a, mtab);
-}
-template <bool WIDE, int V>
-__global__ __launch_bounds__(256) void dp_seed_kernel_o3(FmIndexDev fm, DpPipeArgs a)
-{
-    __shared__ __attribute__((aligned(16))) uint32_t mtab[MaskTabSize<WIDE>::value];
-    init_mask_table<WIDE>(mtab);
-    dp_seed_body<WIDE, V>(fm, a, mtab);
 }
 
 template <bool WIDE>
@@ -152,18 +124,8 @@ static inline unsigned nblk(uint64_t n) { return (unsigned)((n + 255) / 256); }
 hipError_t launch_dp_seeds(const FmIndexDev& fm, const DpPipeArgs& a, hipStream_t stream)
 {
     if(a.n_reqs == 0) return hipSuccess;
-    const dim3 g(nblk((uint64_t)a.n_reqs * 2)), b(256);
-    int v = 0;
-    if(const char* e = std::getenv("LRSC_DP_SEED_VARIANT")) v = std::atoi(e);
-#define LRSC_SEEDV(N) case N: if(fm.wide) hipLaunchKernelGGL((dp_seed_kernel_o3<true, N>), g, b, 0, stream, fm, a); \
-                              else        hipLaunchKernelGGL((dp_seed_kernel_o3<false, N>), g, b, 0, stream, fm, a); break;
-    switch(v) {
-        LRSC_SEEDV(1) LRSC_SEEDV(2) LRSC_SEEDV(3) LRSC_SEEDV(4) LRSC_SEEDV(5)
-        default:
-            if(fm.wide) hipLaunchKernelGGL(dp_seed_kernel<true>, g, b, 0, stream, fm, a);
-            else        hipLaunchKernelGGL(dp_seed_kernel<false>, g, b, 0, stream, fm, a);
-    }
-#undef LRSC_SEEDV
+    if(fm.wide) hipLaunchKernelGGL(dp_seed_kernel<true>, dim3(nblk((uint64_t)a.n_reqs * 2)), dim3(256), 0, stream, fm, a);
+    else        hipLaunchKernelGGL(dp_seed_kernel<false>, dim3(nblk((uint64_t)a.n_reqs * 2)), dim3(256), 0, stream, fm, a);
     return hipGetLastError();
 }
 

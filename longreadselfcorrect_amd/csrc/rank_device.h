@@ -261,6 +261,137 @@ __host__ __device__ __forceinline__ IvT<typename Lay<WIDE>::pos_t> update_interv
     return out;
 }
 
+// ---------------------------------------------------------------------------------------
+// updateInterval with the block's base count fetched by its own dword load (address = block + 4 * code) instead of a
+// select over the four loaded counters.  Why: with the select chain, ROCm 7.2 -O3 lowers `code == 0 ? x : code == 1 ? y :
+// code == 2 ? z : w` over just-loaded registers into exec-masked branches in some kernels (dp_seed_kernel in round 1,
+// the state-machine R-phase in round 2), and those kernels then return intervals that are off by a constant for
+// code 3 ('T') -- traced on the GPU against the CPU run of the same source (tools/sm_trace.py).  The extra load hits
+// the line that is being fetched anyway.  Counts never reach the flag bit (N < 2^31 for Block32, < 2^63 for Block64),
+// so the flag is masked off for every code.
+// ---------------------------------------------------------------------------------------
+template <bool WIDE>
+__host__ __device__ __forceinline__ uint64_t block_base(const void* blocks, uint64_t b, uint32_t code)
+{
+    if(WIDE) return reinterpret_cast<const uint64_t*>(reinterpret_cast<const Block64*>(blocks) + b)[code] & ~kFlag64;
+    return reinterpret_cast<const uint32_t*>(reinterpret_cast<const Block32*>(blocks) + b)[code] & ~kFlag32;
+}
+// symbols equal to `code` among the first `off` symbols of the block (mask row given), without the base count
+template <bool WIDE>
+__host__ __device__ __forceinline__ uint32_t block_popc(const typename Lay<WIDE>::Regs& r, uint32_t code, const uint32_t* __restrict__ mrow)
+{
+    const uint32_t L = (code & 1u) ? 0u : 0xFFFFFFFFu;
+    const uint32_t H = (code & 2u) ? 0u : 0xFFFFFFFFu;
+    uint32_t c = 0;
+    if(WIDE) {
+        const uint4 m0 = *reinterpret_cast<const uint4*>(mrow);
+        c += __builtin_popcount((r.q[2].x ^ L) & (r.q[3].x ^ H) & m0.x);
+        c += __builtin_popcount((r.q[2].y ^ L) & (r.q[3].y ^ H) & m0.y);
+        c += __builtin_popcount((r.q[2].z ^ L) & (r.q[3].z ^ H) & m0.z);
+        c += __builtin_popcount((r.q[2].w ^ L) & (r.q[3].w ^ H) & m0.w);
+    } else {
+        const uint4 m0 = *reinterpret_cast<const uint4*>(mrow);
+        const uint2 m1 = *reinterpret_cast<const uint2*>(mrow + 4);
+        c += __builtin_popcount((r.q[1].x ^ L) & (r.q[1].z ^ H) & m0.x);
+        c += __builtin_popcount((r.q[1].y ^ L) & (r.q[1].w ^ H) & m0.y);
+        c += __builtin_popcount((r.q[2].x ^ L) & (r.q[2].z ^ H) & m0.z);
+        c += __builtin_popcount((r.q[2].y ^ L) & (r.q[2].w ^ H) & m0.w);
+        c += __builtin_popcount((r.q[3].x ^ L) & (r.q[3].z ^ H) & m1.x);
+        c += __builtin_popcount((r.q[3].y ^ L) & (r.q[3].w ^ H) & m1.y);
+    }
+    return c;
+}
+template <bool WIDE>
+__host__ __device__ __forceinline__ IvT<typename Lay<WIDE>::pos_t> update_interval_b(const StrandC<typename Lay<WIDE>::pos_t>& s, uint32_t code,
+                                                                             IvT<typename Lay<WIDE>::pos_t> iv,
+                                                                             const uint32_t* __restrict__ mtab, uint32_t& n_blk)
+{
+    using L = Lay<WIDE>;
+    using P = typename L::pos_t;
+    const P pl = iv.lo;            // (lower - 1) + 1
+    const P pu = iv.hi + 1;        // upper + 1
+    const P bl = pl / L::kSyms, bu = pu / L::kSyms;
+    const uint32_t ol = (uint32_t)(pl - bl * L::kSyms), ou = (uint32_t)(pu - bu * L::kSyms);
+    typename L::Regs ra, rb;
+    L::load(s.blocks, bl, ra);
+    L::load(s.blocks, bu, rb);                     // same line as ra in the common case: an L1 hit
+    const uint64_t base_a = block_base<WIDE>(s.blocks, bl, code);
+    const uint64_t base_b = block_base<WIDE>(s.blocks, bu, code);
+    uint64_t ca = base_a + block_popc<WIDE>(ra, code, mtab + ol * L::kRow);
+    uint64_t cb = base_b + block_popc<WIDE>(rb, code, mtab + ou * L::kRow);
+    if(code == 0) {
+        if(ol != 0 && L::flagged(ra)) ca -= dollars_in_c(s, (uint64_t)bl * L::kSyms, (uint64_t)bl * L::kSyms + ol);
+        if(ou != 0 && L::flagged(rb)) cb -= dollars_in_c(s, (uint64_t)bu * L::kSyms, (uint64_t)bu * L::kSyms + ou);
+    }
+    const P pb = pred_of(s, code);
+    IvT<P> out;
+    out.lo = pb + (P)ca;
+    out.hi = pb + (P)cb - 1;
+    n_blk += (bl == bu) ? 1u : 2u;
+    return out;
+}
+
+// updateInterval for all four codes of one strand at once (getFMIndexExtensions, LongReadCorrectByOverlap.cpp:687-698):
+// the four Occ(c, lo - 1) come from one block and the four Occ(c, hi) from one block, whatever c is.
+template <bool WIDE>
+__host__ __device__ __forceinline__ void block_popc4(const typename Lay<WIDE>::Regs& r, const uint32_t* __restrict__ mrow, uint32_t c[4])
+{
+    uint32_t lo[6], hi[6], m[6];
+    if(WIDE) {
+        const uint4 m0 = *reinterpret_cast<const uint4*>(mrow);
+        lo[0] = r.q[2].x; lo[1] = r.q[2].y; lo[2] = r.q[2].z; lo[3] = r.q[2].w; lo[4] = 0; lo[5] = 0;
+        hi[0] = r.q[3].x; hi[1] = r.q[3].y; hi[2] = r.q[3].z; hi[3] = r.q[3].w; hi[4] = 0; hi[5] = 0;
+        m[0] = m0.x; m[1] = m0.y; m[2] = m0.z; m[3] = m0.w; m[4] = 0; m[5] = 0;
+    } else {
+        const uint4 m0 = *reinterpret_cast<const uint4*>(mrow);
+        const uint2 m1 = *reinterpret_cast<const uint2*>(mrow + 4);
+        lo[0] = r.q[1].x; lo[1] = r.q[1].y; lo[2] = r.q[2].x; lo[3] = r.q[2].y; lo[4] = r.q[3].x; lo[5] = r.q[3].y;
+        hi[0] = r.q[1].z; hi[1] = r.q[1].w; hi[2] = r.q[2].z; hi[3] = r.q[2].w; hi[4] = r.q[3].z; hi[5] = r.q[3].w;
+        m[0] = m0.x; m[1] = m0.y; m[2] = m0.z; m[3] = m0.w; m[4] = m1.x; m[5] = m1.y;
+    }
+    c[0] = c[1] = c[2] = c[3] = 0;
+#pragma unroll
+    for(int w = 0; w < (WIDE ? 4 : 6); ++w) {
+        const uint32_t l = lo[w], h = hi[w], mk = m[w];
+        c[0] += __builtin_popcount(~l & ~h & mk);
+        c[1] += __builtin_popcount(l & ~h & mk);
+        c[2] += __builtin_popcount(~l & h & mk);
+        c[3] += __builtin_popcount(l & h & mk);
+    }
+}
+template <bool WIDE>
+__host__ __device__ __forceinline__ void update_interval_all(const StrandC<typename Lay<WIDE>::pos_t>& s, IvT<typename Lay<WIDE>::pos_t> iv,
+                                                             const uint32_t* __restrict__ mtab, IvT<typename Lay<WIDE>::pos_t> out[4], uint32_t& n_blk)
+{
+    using L = Lay<WIDE>;
+    using P = typename L::pos_t;
+    const P pl = iv.lo, pu = iv.hi + 1;
+    const P bl = pl / L::kSyms, bu = pu / L::kSyms;
+    const uint32_t ol = (uint32_t)(pl - bl * L::kSyms), ou = (uint32_t)(pu - bu * L::kSyms);
+    typename L::Regs ra, rb;
+    L::load(s.blocks, bl, ra);
+    L::load(s.blocks, bu, rb);
+    uint32_t pa[4], pb4[4];
+    block_popc4<WIDE>(ra, mtab + ol * L::kRow, pa);
+    block_popc4<WIDE>(rb, mtab + ou * L::kRow, pb4);
+    uint64_t ba[4], bb[4];
+    if(WIDE) {
+        ba[0] = Lay<true>::u64(ra.q[0].x, ra.q[0].y) & ~kFlag64; ba[1] = Lay<true>::u64(ra.q[0].z, ra.q[0].w); ba[2] = Lay<true>::u64(ra.q[1].x, ra.q[1].y); ba[3] = Lay<true>::u64(ra.q[1].z, ra.q[1].w);
+        bb[0] = Lay<true>::u64(rb.q[0].x, rb.q[0].y) & ~kFlag64; bb[1] = Lay<true>::u64(rb.q[0].z, rb.q[0].w); bb[2] = Lay<true>::u64(rb.q[1].x, rb.q[1].y); bb[3] = Lay<true>::u64(rb.q[1].z, rb.q[1].w);
+    } else {
+        ba[0] = ra.q[0].x & ~kFlag32; ba[1] = ra.q[0].y; ba[2] = ra.q[0].z; ba[3] = ra.q[0].w;
+        bb[0] = rb.q[0].x & ~kFlag32; bb[1] = rb.q[0].y; bb[2] = rb.q[0].z; bb[3] = rb.q[0].w;
+    }
+    uint64_t ca0 = ba[0] + pa[0], cb0 = bb[0] + pb4[0];
+    if(ol != 0 && L::flagged(ra)) ca0 -= dollars_in_c(s, (uint64_t)bl * L::kSyms, (uint64_t)bl * L::kSyms + ol);
+    if(ou != 0 && L::flagged(rb)) cb0 -= dollars_in_c(s, (uint64_t)bu * L::kSyms, (uint64_t)bu * L::kSyms + ou);
+    out[0].lo = s.c1 + (P)ca0;               out[0].hi = s.c1 + (P)cb0 - 1;
+    out[1].lo = s.c2 + (P)(ba[1] + pa[1]);   out[1].hi = s.c2 + (P)(bb[1] + pb4[1]) - 1;
+    out[2].lo = s.c3 + (P)(ba[2] + pa[2]);   out[2].hi = s.c3 + (P)(bb[2] + pb4[2]) - 1;
+    out[3].lo = s.c4 + (P)(ba[3] + pa[3]);   out[3].hi = s.c4 + (P)(bb[3] + pb4[3]) - 1;
+    n_blk += (bl == bu) ? 1u : 2u;
+}
+
 // BWTAlgorithms::initInterval (BWTAlgorithms.h:136-140): Occ(b, N-1) is the symbol total.
 template <class P>
 __host__ __device__ __forceinline__ IvT<P> init_interval(const StrandC<P>& s, uint32_t code)

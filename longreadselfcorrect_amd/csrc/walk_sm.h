@@ -23,18 +23,79 @@
 
 #include "correct_dev.h"
 #include "walk_device.h"
+#include "ws_layout.h"
 
 namespace lrsc {
 
 #define LRSC_SM __host__ __device__ inline
 
-enum : uint32_t { kReqNone = 0, kReqRank = 1, kReqTab = 2 };
+
+// Byte-string helpers for the stitching code.  A plain `for(t) d[t] = s[t]` over uint8_t pointers must assume d aliases
+// everything: every iteration waits for its own load (a global-memory round trip per byte).  These move 16 bytes per
+// round trip: the loads of a batch are independent.
+LRSC_SM void copy_codes(uint8_t* __restrict__ d, const uint8_t* __restrict__ s, uint32_t n)
+{
+    uint32_t t = 0;
+    for(; t + 16 <= n; t += 16) {
+        uint8_t v[16];
+#pragma unroll
+        for(int j = 0; j < 16; ++j) v[j] = s[t + j];
+#pragma unroll
+        for(int j = 0; j < 16; ++j) d[t + j] = v[j];
+    }
+    for(; t < n; ++t) d[t] = s[t];
+}
+// d[t] = 3 - s_last[-t], t = 0..n-1 (reverse complement, reading backwards from s_last)
+LRSC_SM void copy_codes_rc(uint8_t* __restrict__ d, const uint8_t* __restrict__ s_last, uint32_t n)
+{
+    uint32_t t = 0;
+    for(; t + 16 <= n; t += 16) {
+        uint8_t v[16];
+#pragma unroll
+        for(int j = 0; j < 16; ++j) v[j] = *(s_last - (int64_t)(t + j));
+#pragma unroll
+        for(int j = 0; j < 16; ++j) d[t + j] = (uint8_t)(3 - v[j]);
+    }
+    for(; t < n; ++t) d[t] = (uint8_t)(3 - *(s_last - (int64_t)t));
+}
+// d[t] = path character (from + t), t = 0..n-1 (2-bit packed words)
+LRSC_SM void unpack_path(uint8_t* __restrict__ d, const uint32_t* __restrict__ words, uint32_t from, uint32_t n)
+{
+    uint32_t t = 0;
+    while(t < n) {
+        const uint32_t j = from + t;
+        const uint32_t w = words[j >> 4];
+        const uint32_t in_word = 16u - (j & 15u);
+        const uint32_t m = in_word < n - t ? in_word : n - t;
+        for(uint32_t u = 0; u < m; ++u) d[t + u] = (uint8_t)((w >> (2 * ((j + u) & 15u))) & 3u);
+        t += m;
+    }
+}
+// d[t] = 3 - path character (last - t), t = 0..n-1
+LRSC_SM void unpack_path_rc(uint8_t* __restrict__ d, const uint32_t* __restrict__ words, uint32_t last, uint32_t n)
+{
+    uint32_t t = 0;
+    while(t < n) {
+        const uint32_t j = last - t;
+        const uint32_t w = words[j >> 4];
+        const uint32_t in_word = (j & 15u) + 1u;
+        const uint32_t m = in_word < n - t ? in_word : n - t;
+        for(uint32_t u = 0; u < m; ++u) d[t + u] = (uint8_t)(3u - ((w >> (2 * ((j - u) & 15u))) & 3u));
+        t += m;
+    }
+}
+
+enum : uint32_t { kReqNone = 0, kReqRank = 1, kReqTab = 2, kReqExt = 3 };
 enum : uint32_t { kReqDoA = 1u, kReqDoB = 2u, kReqSwap = 4u };
 
 // A pending FM-index request of one lane.
 //   kReqRank: a = updateInterval(X, ca, a) if DoA, b = updateInterval(Y, cb, b) if DoB, with (X, Y) = (rBWT, BWT), or
 //             (BWT, rBWT) when Swap is set (SelectFreqsOfrange searches the k-mer itself, not its reverse).
 //   kReqTab:  entry `code` of k-mer table `tab` -> a = {fwd.lo, fwd.hi}, b = {rvc.lo, rvc.hi}
+//   kReqExt:  getFMIndexExtensions' rank queries for all four bases at once: for base x, a_x = updateInterval(rBWT, x, a)
+//             if DoA and b_x = updateInterval(BWT, 3 - x, b) if DoB.  The four bases of a strand read the SAME two rank
+//             blocks (Occ(., lo - 1) and Occ(., hi)), so this costs the memory traffic of one kReqRank; the sixteen
+//             results go straight to the lane's `ex` slots.
 template <class P>
 struct SmReq {
     uint32_t kind, flags;
@@ -48,7 +109,8 @@ enum : uint32_t {
     PC_FS = 1,            // find_suffix over a leaf list: waiting for a table entry or a step
     PC_SF,                // SelectFreqsOfrange
     PC_ROOT_DONE,
-    PC_EXT,               // getFMIndexExtensions of leaf att_i: waiting for base att_b
+    PC_EXT,               // getFMIndexExtensions of leaf att_i: waiting for the R-phase
+    PC_EXT_READY,         // ... answered: waits for the wavefront's step gate, then the acceptance ladder + children
     PC_ATT_DONE,
     PC_AFTER_SF_A,
     PC_POST,
@@ -65,11 +127,24 @@ enum : uint32_t {
     PC_DONE
 };
 
+// debugging aid: one 14-word record per sweep of the traced read (the same on the device and in the CPU harness)
+template <class P>
+__host__ __device__ inline void sm_trace(uint32_t* trace, uint32_t cap, uint32_t& pos, uint32_t pc, bool have, const SmReq<P>& rq, const SmReq<P>& res)
+{
+    if(trace == nullptr || pos + 14 > cap) return;
+    uint32_t* t = trace + pos;
+    t[0] = pc; t[1] = have ? rq.kind : 0u; t[2] = rq.flags; t[3] = rq.ca | (rq.cb << 8); t[4] = rq.tab; t[5] = rq.code;
+    t[6] = (uint32_t)rq.a_lo; t[7] = (uint32_t)rq.a_hi; t[8] = (uint32_t)rq.b_lo; t[9] = (uint32_t)rq.b_hi;
+    t[10] = (uint32_t)res.a_lo; t[11] = (uint32_t)res.a_hi; t[12] = (uint32_t)res.b_lo; t[13] = (uint32_t)res.b_hi;
+    pos += 14;
+}
+
 // The R-phase for one lane: answers rq into res (a_lo, a_hi, b_lo, b_hi).  All lanes of a wavefront call this together.
 template <bool WIDE>
 __host__ __device__ __forceinline__ void sm_answer(const FmIndexDev& fm, const StrandC<typename Lay<WIDE>::pos_t>& sF,
                                                    const StrandC<typename Lay<WIDE>::pos_t>& sR, const uint32_t* mtab,
                                                    const SmReq<typename Lay<WIDE>::pos_t>& rq, SmReq<typename Lay<WIDE>::pos_t>& res,
+                                                   typename Lay<WIDE>::pos_t* ex, uint32_t ex_stride,
                                                    uint32_t& n_rank, uint32_t& n_blk, uint32_t& n_tab)
 {
     using P = typename Lay<WIDE>::pos_t;
@@ -97,12 +172,22 @@ __host__ __device__ __forceinline__ void sm_answer(const FmIndexDev& fm, const S
         SA.c1 = swap ? sR.c1 : sF.c1; SA.c2 = swap ? sR.c2 : sF.c2; SA.c3 = swap ? sR.c3 : sF.c3; SA.c4 = swap ? sR.c4 : sF.c4; SA.n = swap ? sR.n : sF.n;
         SB.c1 = swap ? sF.c1 : sR.c1; SB.c2 = swap ? sF.c2 : sR.c2; SB.c3 = swap ? sF.c3 : sR.c3; SB.c4 = swap ? sF.c4 : sR.c4; SB.n = swap ? sF.n : sR.n;
         if(rq.flags & kReqDoA) {
-            const IvT<P> o = update_interval<WIDE, false>(SA, rq.ca, IvT<P>{rq.a_lo, rq.a_hi}, mtab, n_blk);
+            const IvT<P> o = update_interval_b<WIDE>(SA, rq.ca, IvT<P>{rq.a_lo, rq.a_hi}, mtab, n_blk);
             res.a_lo = o.lo; res.a_hi = o.hi; n_rank += 2;
         }
         if(rq.flags & kReqDoB) {
-            const IvT<P> o = update_interval<WIDE, false>(SB, rq.cb, IvT<P>{rq.b_lo, rq.b_hi}, mtab, n_blk);
+            const IvT<P> o = update_interval_b<WIDE>(SB, rq.cb, IvT<P>{rq.b_lo, rq.b_hi}, mtab, n_blk);
             res.b_lo = o.lo; res.b_hi = o.hi; n_rank += 2;
+        }
+    } else if(rq.kind == kReqExt) {
+        // element (x * 4 + f) of the lane's ex slots: f = 0,1 the rBWT pair of base x, f = 2,3 the BWT pair of base x
+        IvT<P> fo[4], ro[4];
+        for(uint32_t x = 0; x < 4; ++x) { fo[x] = IvT<P>{rq.a_lo, rq.a_hi}; ro[x] = IvT<P>{rq.b_lo, rq.b_hi}; }
+        if(rq.flags & kReqDoA) { update_interval_all<WIDE>(sF, IvT<P>{rq.a_lo, rq.a_hi}, mtab, fo, n_blk); n_rank += 8; }
+        if(rq.flags & kReqDoB) { update_interval_all<WIDE>(sR, IvT<P>{rq.b_lo, rq.b_hi}, mtab, ro, n_blk); n_rank += 8; }
+        for(uint32_t x = 0; x < 4; ++x) {
+            ex[(x * 4u + 0u) * ex_stride] = fo[x].lo; ex[(x * 4u + 1u) * ex_stride] = fo[x].hi;
+            ex[(x * 4u + 2u) * ex_stride] = ro[3u - x].lo; ex[(x * 4u + 3u) * ex_stride] = ro[3u - x].hi;      // BWT strand: code 3 - x
         }
     }
 }
@@ -115,85 +200,90 @@ struct ReadSM {
     // ---- wave-uniform context (pointers into kernel arguments) ----
     const FmIndexDev* __restrict__ fm;
     const CorrectArgs* __restrict__ A;
-    StrandC<P> sF, sR;
+    const StrandC<P>* sFp;            // rBWT / BWT constants (the caller's wave-uniform copies)
+    const StrandC<P>* sRp;
 
     // ---- the read ----
     uint32_t r;
-    const uint8_t* read;
-    const int32_t* seeds;
-    uint32_t n_seeds, rlen;
-    uint8_t* out;
-    uint32_t* piece_start;
-    uint8_t* ws;
-    ReadWork rw;
-    // chain state (pieceVec.back()'s SeedFeature fields + iterTarget)
+    uint64_t rs;                      // first base of the read in A->codes
+    uint32_t n_seeds;
+    uint8_t* ws;                      // the read's workspace
+    uint32_t lq_max, pathw;           // what its variable-size regions are laid out for (ws_layout.h)
+    // chain state (pieceVec.back()'s SeedFeature fields + iterTarget); the integer counters live in A->out[r].c[]
     int32_t S_seedLen, S_end, S_endBest, S_maxFixed;
     bool S_isRepeat;
     uint32_t it;
     int32_t next, firstType;
     uint32_t out_len, n_pieces;
-    int64_t correctedLen, totalWalkNum, highErrorNum, exceedDepthNum, exceedLeaveNum, FMNum, DPNum, seedDis;
     int32_t error;
     uint32_t state;               // kReadDone / kReadParked / kReadYield
     uint32_t walks_here;
-    uint64_t steps, steps0;
+    uint32_t steps, steps0;
     // current walk geometry
     int32_t T_start, T_len, interval, k, trg_len;
     bool T_isRepeat, rtou;
     uint32_t Lq, initk;
-    uint64_t min_SA_threshold, maxIndelSize, maxLength, minLength, currentLength, currentKmerSize;
+    uint32_t min_SA_threshold, maxIndelSize, maxLength, minLength, currentLength, currentKmerSize;
     uint32_t maxOverlap;
-    uint32_t n_cur, n_nxt, n_results, n9f, n9r;
+    uint32_t n_cur, n_nxt, n_results;
     uint32_t slot_free;           // free ring/path slots (bit mask; a leaf's ring and path slot ids are always equal)
     bool ended;
     // ---- state machine ----
     uint32_t pc;
     SmReq<P> req;
-    // FS
-    uint32_t fs_list, fs_n, fs_j, fs_len, fs_t, fs_ret;
-    bool fs_start, fs_fb, fs_rb, fs_setk;
-    P fs_flo, fs_fhi, fs_rlo, fs_rhi;
-    uint64_t fs_suf_lo, fs_suf_hi;
-    // SF
-    uint32_t sf_list, sf_n, sf_j, sf_t, sf_i, sf_ret, sf_phase;
-    uint32_t sf_LB, sf_UB;
+    // one register set for the three searches that are never active together (FS / SF / PREP)
+    uint32_t m_list, m_n, m_j, m_len, m_t, m_ret;
+    bool m_start, m_fb, m_rb, m_flag;          // m_flag: FS "set currentKmerSize", PREP "inside the target seed"
+    P m_flo, m_fhi, m_rlo, m_rhi;
+    uint64_t m_suf_lo, m_suf_hi;
+    // SF only
+    uint32_t sf_i, sf_phase, sf_LB, sf_UB, sf_result;
     int32_t sf_max;
-    uint64_t sf_result;
-    bool sf_start, sf_fb, sf_rb;
-    P sf_flo, sf_fhi, sf_rlo, sf_rhi;
-    uint64_t sf_suf_lo, sf_suf_hi;
     // ATT / EXT
-    uint32_t att_no, att_i, att_b;
+    uint32_t att_no, att_i;
     double att_minErr;
-    P ex_flo[4], ex_fhi[4], ex_rlo[4], ex_rhi[4];
-    // PREP
-    uint32_t prep_i, prep_s, prep_kmax;
-    bool prep_start, prep_term, prep_fb, prep_rb;
-    P prep_flo, prep_fhi, prep_rlo, prep_rhi;
+    P* ex;                        // 16 values (4 extension pairs), element e of this lane at ex[e * ex_stride]
+    uint32_t ex_stride;
     // accounting
     uint32_t n_rank, n_blk, n_tab;
 
-    // ---- workspace views ----
-    LRSC_SM SortItem* it9f() const { return reinterpret_cast<SortItem*>(ws + rw.o_item9f); }
-    LRSC_SM SortItem* it9r() const { return reinterpret_cast<SortItem*>(ws + rw.o_item9r); }
-    LRSC_SM uint16_t* next9f() const { return reinterpret_cast<uint16_t*>(ws + rw.o_next9f); }
-    LRSC_SM uint16_t* next9r() const { return reinterpret_cast<uint16_t*>(ws + rw.o_next9r); }
-    LRSC_SM uint16_t* head9f() const { return reinterpret_cast<uint16_t*>(ws + rw.o_head9); }
-    LRSC_SM uint16_t* head9r() const { return reinterpret_cast<uint16_t*>(ws + rw.o_head9) + 256; }
-    LRSC_SM uint16_t* head5() const { return reinterpret_cast<uint16_t*>(ws + rw.o_head5); }
-    LRSC_SM uint16_t* next5() const { return reinterpret_cast<uint16_t*>(ws + rw.o_next5); }
-    LRSC_SM uint8_t* flags5() const { return ws + rw.o_flags5; }
-    LRSC_SM P* term() const { return reinterpret_cast<P*>(ws + rw.o_term); }
-    LRSC_SM LeafT* cur() const { return reinterpret_cast<LeafT*>(ws + rw.o_leaves); }
-    LRSC_SM LeafT* nxt() const { return reinterpret_cast<LeafT*>(ws + rw.o_leaves) + 32; }
+    // ---- workspace views (ws_layout.h: fixed-size regions at constant offsets, the rest from lq_max / pathw) ----
+    static constexpr uint32_t kLB = (uint32_t)sizeof(Leaf<P>);
+    LRSC_SM WsVar var() const { return ws_var_offsets(kLB, (uint32_t)sizeof(P), lq_max, A->seed_size, pathw); }
+    LRSC_SM uint32_t n9cap() const { return (lq_max > 16u ? lq_max : 16u) - A->seed_size + 1u; }
+    LRSC_SM uint32_t lqcap() const { return lq_max > 16u ? lq_max : 16u; }
+    LRSC_SM SortItem* it9f() const { return reinterpret_cast<SortItem*>(ws + ws_var_base(kLB)); }
+    LRSC_SM SortItem* it9r() const { return reinterpret_cast<SortItem*>(ws + ws_var_base(kLB)) + n9cap(); }
+    LRSC_SM P* term() const { return reinterpret_cast<P*>(ws + ws_var_base(kLB) + n9cap() * 32u); }
+    LRSC_SM uint32_t o_paths() const { return ws_al16(ws_var_base(kLB) + n9cap() * 32u + lqcap() * 4u * (uint32_t)sizeof(P)); }
+    LRSC_SM uint32_t* paths() const { return reinterpret_cast<uint32_t*>(ws + o_paths()); }
+    LRSC_SM uint32_t* rpaths() const { return paths() + 32u * pathw; }
+    LRSC_SM uint32_t* best() const { return paths() + (32u + kMaxResults) * pathw; }
+    LRSC_SM uint32_t o_next9f() const { return o_paths() + (32u + kMaxResults + 1u) * pathw * 4u; }
+    LRSC_SM uint16_t* next9f() const { return reinterpret_cast<uint16_t*>(ws + o_next9f()); }
+    LRSC_SM uint16_t* next9r() const { return next9f() + n9cap(); }
+    LRSC_SM uint16_t* next5() const { return next9f() + 2u * n9cap(); }
+    LRSC_SM uint8_t* flags5() const { return ws + o_next9f() + 4u * n9cap() + 2u * (lqcap() - 4u); }
+    LRSC_SM uint8_t* q() const { return flags5() + (lqcap() - 4u); }
+    LRSC_SM uint8_t* dpq() const { return q() + lqcap(); }
+    LRSC_SM uint16_t* head9f() const { return reinterpret_cast<uint16_t*>(ws + ws_fixed_head9(kLB)); }
+    LRSC_SM uint16_t* head9r() const { return head9f() + 256; }
+    LRSC_SM uint16_t* head5() const { return reinterpret_cast<uint16_t*>(ws + ws_fixed_head5(kLB)); }
+    LRSC_SM LeafT* cur() const { return reinterpret_cast<LeafT*>(ws); }
+    LRSC_SM LeafT* nxt() const { return reinterpret_cast<LeafT*>(ws) + 32; }
     LRSC_SM LeafT* leaves(uint32_t list) const { return list ? nxt() : cur(); }
-    LRSC_SM double* rings() const { return reinterpret_cast<double*>(ws + rw.o_rings); }
-    LRSC_SM uint32_t* paths() const { return reinterpret_cast<uint32_t*>(ws + rw.o_paths); }
-    LRSC_SM uint32_t* rpaths() const { return reinterpret_cast<uint32_t*>(ws + rw.o_paths) + (uint64_t)32 * rw.pathw; }
-    LRSC_SM WalkResultRec* results() const { return reinterpret_cast<WalkResultRec*>(ws + rw.o_results); }
-    LRSC_SM uint8_t* q() const { return ws + rw.o_query; }
-    LRSC_SM uint32_t* best() const { return reinterpret_cast<uint32_t*>(ws + rw.o_best); }
-    LRSC_SM uint8_t* dpq() const { return ws + rw.o_dpq; }
+    LRSC_SM double* rings() const { return reinterpret_cast<double*>(ws + ws_fixed_rings(kLB)); }
+    LRSC_SM WalkResultRec* results() const { return reinterpret_cast<WalkResultRec*>(ws + ws_fixed_results(kLB)); }
+    // read-level views, recomputed where needed (used between walks only)
+    LRSC_SM const uint8_t* read() const { return A->codes + rs; }
+    LRSC_SM const int32_t* seeds() const { return A->seeds + seed_slab(rs, r, A->min_k) * kSeedInts; }
+    LRSC_SM uint8_t* out() const { return A->out_codes + A->work[r].out_off; }
+    LRSC_SM uint32_t* piece_start() const { return A->piece_start + A->work[r].piece_off; }
+    LRSC_SM uint32_t out_cap() const { return A->work[r].out_cap; }
+    LRSC_SM int64_t& ctr(int j) const { return A->out[r].c[j]; }
+    LRSC_SM const StrandC<P>& sF() const { return *sFp; }
+    LRSC_SM const StrandC<P>& sR() const { return *sRp; }
+    LRSC_SM P& exv(uint32_t b, uint32_t f) const { return ex[(b * 4u + f) * ex_stride]; }
 
     LRSC_SM uint32_t seedSize() const { return A->seed_size; }
     LRSC_SM uint32_t minOverlap() const { return A->min_overlap; }
@@ -240,64 +330,64 @@ struct ReadSM {
     }
 
     // =========================================================================================================
-    // FS: findInterval of the suffix of length fs_len of every leaf of a list (refineSAInterval .cpp:355-369,
+    // FS: findInterval of the suffix of length m_len of every leaf of a list (refineSAInterval .cpp:355-369,
     // initialRootNode :108-124); fwd = reverse(kmer) in the rBWT, rvc = revcomp(kmer) in the BWT.
     // =========================================================================================================
     LRSC_SM void fs_begin(uint32_t list, uint32_t n, uint32_t len, uint32_t ret, bool set_k)
     {
-        fs_list = list; fs_n = n; fs_len = len; fs_ret = ret; fs_j = 0; fs_start = true; fs_setk = set_k;
+        m_list = list; m_n = n; m_len = len; m_ret = ret; m_j = 0; m_start = true; m_flag = set_k;
         pc = PC_FS;
         fs_advance();
     }
     LRSC_SM void fs_advance()
     {
         while(true) {
-            if(fs_start) {
-                if(fs_j >= fs_n) {
-                    if(fs_setk) currentKmerSize = fs_len;
-                    pc = fs_ret;
+            if(m_start) {
+                if(m_j >= m_n) {
+                    if(m_flag) currentKmerSize = m_len;
+                    pc = m_ret;
                     return;
                 }
-                const LeafT& lf = leaves(fs_list)[fs_j];
-                fs_suf_lo = lf.suf_lo; fs_suf_hi = lf.suf_hi;
-                fs_start = false;
-                fs_fb = false; fs_rb = false;
-                const int tb = best_table(fs_len);
+                const LeafT& lf = leaves(m_list)[m_j];
+                m_suf_lo = lf.suf_lo; m_suf_hi = lf.suf_hi;
+                m_start = false;
+                m_fb = false; m_rb = false;
+                const int tb = best_table(m_len);
                 if(tb >= 0) {
                     const uint32_t tk = table_k(tb);
-                    fs_t = tk;
-                    req_tab((uint32_t)tb, suf_code(fs_suf_lo, fs_suf_hi, fs_len, 0, tk));
-                    fs_t |= 0x80000000u;                         // marks "table entry pending"
+                    m_t = tk;
+                    req_tab((uint32_t)tb, suf_code(m_suf_lo, m_suf_hi, m_len, 0, tk));
+                    m_t |= 0x80000000u;                         // marks "table entry pending"
                     return;
                 }
                 // no table: the first character is initInterval on both strands
-                const uint32_t c = suf_at(fs_suf_lo, fs_suf_hi, fs_len, 0);
-                const IvT<P> f = init_interval<P>(sF, c), rr = init_interval<P>(sR, 3u - c);
-                fs_flo = f.lo; fs_fhi = f.hi; fs_rlo = rr.lo; fs_rhi = rr.hi;
-                fs_t = 1;
+                const uint32_t c = suf_at(m_suf_lo, m_suf_hi, m_len, 0);
+                const IvT<P> f = init_interval<P>(sF(), c), rr = init_interval<P>(sR(), 3u - c);
+                m_flo = f.lo; m_fhi = f.hi; m_rlo = rr.lo; m_rhi = rr.hi;
+                m_t = 1;
                 n_rank += 2;
             }
-            if(fs_t < fs_len && !(fs_fb && fs_rb)) {
-                const uint32_t c = suf_at(fs_suf_lo, fs_suf_hi, fs_len, fs_t);
-                req_rank(fs_flo, fs_fhi, c, !fs_fb, fs_rlo, fs_rhi, 3u - c, !fs_rb, false);
+            if(m_t < m_len && !(m_fb && m_rb)) {
+                const uint32_t c = suf_at(m_suf_lo, m_suf_hi, m_len, m_t);
+                req_rank(m_flo, m_fhi, c, !m_fb, m_rlo, m_rhi, 3u - c, !m_rb, false);
                 return;
             }
-            LeafT& lf = leaves(fs_list)[fs_j];
-            lf.flo = fs_flo; lf.fhi = fs_fhi; lf.rlo = fs_rlo; lf.rhi = fs_rhi;
-            ++fs_j;
-            fs_start = true;
+            LeafT& lf = leaves(m_list)[m_j];
+            lf.flo = m_flo; lf.fhi = m_fhi; lf.rlo = m_rlo; lf.rhi = m_rhi;
+            ++m_j;
+            m_start = true;
         }
     }
     LRSC_SM void fs_result(const SmReq<P>& res)
     {
-        if(fs_t & 0x80000000u) {                                 // table entry
-            fs_t &= 0x7FFFFFFFu;
-            fs_flo = res.a_lo; fs_fhi = res.a_hi; fs_rlo = res.b_lo; fs_rhi = res.b_hi;
-            fs_fb = fs_flo > fs_fhi; fs_rb = fs_rlo > fs_rhi;
+        if(m_t & 0x80000000u) {                                 // table entry
+            m_t &= 0x7FFFFFFFu;
+            m_flo = res.a_lo; m_fhi = res.a_hi; m_rlo = res.b_lo; m_rhi = res.b_hi;
+            m_fb = m_flo > m_fhi; m_rb = m_rlo > m_rhi;
         } else {
-            if(!fs_fb) { fs_flo = res.a_lo; fs_fhi = res.a_hi; fs_fb = fs_flo > fs_fhi; }
-            if(!fs_rb) { fs_rlo = res.b_lo; fs_rhi = res.b_hi; fs_rb = fs_rlo > fs_rhi; }
-            ++fs_t;
+            if(!m_fb) { m_flo = res.a_lo; m_fhi = res.a_hi; m_fb = m_flo > m_fhi; }
+            if(!m_rb) { m_rlo = res.b_lo; m_rhi = res.b_hi; m_rb = m_rlo > m_rhi; }
+            ++m_t;
         }
         fs_advance();
     }
@@ -309,75 +399,75 @@ struct ReadSM {
     // =========================================================================================================
     LRSC_SM void sf_begin(uint32_t list, uint32_t n, uint64_t LB, uint64_t UB, uint32_t ret)
     {
-        sf_list = list; sf_n = n; sf_LB = (uint32_t)LB; sf_UB = (uint32_t)UB; sf_ret = ret;
-        sf_phase = 1; sf_j = 0; sf_start = true; sf_max = 0;
+        m_list = list; m_n = n; sf_LB = (uint32_t)LB; sf_UB = (uint32_t)UB; m_ret = ret;
+        sf_phase = 1; m_j = 0; m_start = true; sf_max = 0;
         pc = PC_SF;
         sf_advance();
     }
     LRSC_SM void sf_store_leaf()
     {
-        LeafT& lf = leaves(sf_list)[sf_j];
-        lf.tflo = sf_flo; lf.tfhi = sf_fhi; lf.trlo = sf_rlo; lf.trhi = sf_rhi;
-        lf.tmpFreq = (int)(isize(sf_flo, sf_fhi) + isize(sf_rlo, sf_rhi));
+        LeafT& lf = leaves(m_list)[m_j];
+        lf.tflo = m_flo; lf.tfhi = m_fhi; lf.trlo = m_rlo; lf.trhi = m_rhi;
+        lf.tmpFreq = (int)(isize(m_flo, m_fhi) + isize(m_rlo, m_rhi));
         if(lf.tmpFreq > sf_max) sf_max = lf.tmpFreq;
     }
-    LRSC_SM void sf_finish(uint64_t result) { sf_result = result; pc = sf_ret; }
+    LRSC_SM void sf_finish(uint64_t result) { sf_result = result; pc = m_ret; }
     LRSC_SM void sf_advance()
     {
         const uint32_t U = sf_UB, Lw = sf_LB;
         while(true) {
             if(sf_phase == 1) {
-                if(sf_start) {
-                    if(sf_j >= sf_n) {
+                if(m_start) {
+                    if(m_j >= m_n) {
                         if(sf_max - (int)A->freqs_of_kmer_size[sf_LB] < 5) { sf_finish(sf_LB); return; }
                         if(sf_UB == sf_LB) { sf_finish(sf_UB); return; }
-                        sf_phase = 2; sf_i = 1; sf_j = 0; sf_max = 0;
+                        sf_phase = 2; sf_i = 1; m_j = 0; sf_max = 0;
                         continue;
                     }
-                    const LeafT& lf = leaves(sf_list)[sf_j];
-                    sf_suf_lo = lf.suf_lo; sf_suf_hi = lf.suf_hi;
-                    sf_start = false; sf_fb = false; sf_rb = false;
+                    const LeafT& lf = leaves(m_list)[m_j];
+                    m_suf_lo = lf.suf_lo; m_suf_hi = lf.suf_hi;
+                    m_start = false; m_fb = false; m_rb = false;
                     const int tb = best_table(Lw);
                     if(tb >= 0) {
                         // w[t] = 3 - x_t, x_t = character at distance t from the newest one
                         const uint32_t tk = table_k(tb);
                         uint32_t code = 0;
                         for(uint32_t t = 0; t < tk; ++t) {
-                            const uint32_t x = t < 32 ? (uint32_t)(sf_suf_lo >> (2 * t)) & 3u : (uint32_t)(sf_suf_hi >> (2 * (t - 32))) & 3u;
+                            const uint32_t x = t < 32 ? (uint32_t)(m_suf_lo >> (2 * t)) & 3u : (uint32_t)(m_suf_hi >> (2 * (t - 32))) & 3u;
                             code = (code << 2) | (3u - x);
                         }
-                        sf_t = tk | 0x80000000u;
+                        m_t = tk | 0x80000000u;
                         req_tab((uint32_t)tb, code);
                         return;
                     }
-                    const uint32_t x0 = (uint32_t)sf_suf_lo & 3u;
-                    const IvT<P> f = init_interval<P>(sR, x0), rr = init_interval<P>(sF, 3u - x0);
-                    sf_flo = f.lo; sf_fhi = f.hi; sf_rlo = rr.lo; sf_rhi = rr.hi;
-                    sf_t = 1;
+                    const uint32_t x0 = (uint32_t)m_suf_lo & 3u;
+                    const IvT<P> f = init_interval<P>(sR(), x0), rr = init_interval<P>(sF(), 3u - x0);
+                    m_flo = f.lo; m_fhi = f.hi; m_rlo = rr.lo; m_rhi = rr.hi;
+                    m_t = 1;
                     n_rank += 2;
                 }
-                if(sf_t < Lw && !(sf_fb && sf_rb)) {
-                    const uint32_t t = sf_t;
-                    const uint32_t c = t < 32 ? (uint32_t)(sf_suf_lo >> (2 * t)) & 3u : (uint32_t)(sf_suf_hi >> (2 * (t - 32))) & 3u;
-                    req_rank(sf_flo, sf_fhi, c, !sf_fb, sf_rlo, sf_rhi, 3u - c, !sf_rb, true);
+                if(m_t < Lw && !(m_fb && m_rb)) {
+                    const uint32_t t = m_t;
+                    const uint32_t c = t < 32 ? (uint32_t)(m_suf_lo >> (2 * t)) & 3u : (uint32_t)(m_suf_hi >> (2 * (t - 32))) & 3u;
+                    req_rank(m_flo, m_fhi, c, !m_fb, m_rlo, m_rhi, 3u - c, !m_rb, true);
                     return;
                 }
                 sf_store_leaf();
-                ++sf_j;
-                sf_start = true;
+                ++m_j;
+                m_start = true;
             } else {
                 // phase 2: extend every leaf's pair by one more (older) character, no validity check (.cpp:317-318)
-                if(sf_j >= sf_n) {
+                if(m_j >= m_n) {
                     if(sf_max - (int)A->freqs_of_kmer_size[sf_LB + sf_i] < 5) { sf_finish(sf_LB + sf_i); return; }
                     ++sf_i;
                     if(sf_i > sf_UB - sf_LB) { sf_finish(sf_UB); return; }
-                    sf_j = 0; sf_max = 0;
+                    m_j = 0; sf_max = 0;
                     continue;
                 }
-                const LeafT& lf = leaves(sf_list)[sf_j];
+                const LeafT& lf = leaves(m_list)[m_j];
                 const uint32_t b = suf_char(lf, U, (uint32_t)(sf_UB - sf_LB - sf_i));
-                sf_flo = lf.tflo; sf_fhi = lf.tfhi; sf_rlo = lf.trlo; sf_rhi = lf.trhi;
-                req_rank(sf_flo, sf_fhi, b, true, sf_rlo, sf_rhi, 3u - b, true, true);
+                m_flo = lf.tflo; m_fhi = lf.tfhi; m_rlo = lf.trlo; m_rhi = lf.trhi;
+                req_rank(m_flo, m_fhi, b, true, m_rlo, m_rhi, 3u - b, true, true);
                 return;
             }
         }
@@ -385,20 +475,20 @@ struct ReadSM {
     LRSC_SM void sf_result_in(const SmReq<P>& res)
     {
         if(sf_phase == 1) {
-            if(sf_t & 0x80000000u) {
+            if(m_t & 0x80000000u) {
                 // table entry of w: fwd = rBWT state (our r), rvc = BWT state (our f)
-                sf_t &= 0x7FFFFFFFu;
-                sf_rlo = res.a_lo; sf_rhi = res.a_hi; sf_flo = res.b_lo; sf_fhi = res.b_hi;
-                sf_fb = sf_flo > sf_fhi; sf_rb = sf_rlo > sf_rhi;
+                m_t &= 0x7FFFFFFFu;
+                m_rlo = res.a_lo; m_rhi = res.a_hi; m_flo = res.b_lo; m_fhi = res.b_hi;
+                m_fb = m_flo > m_fhi; m_rb = m_rlo > m_rhi;
             } else {
-                if(!sf_fb) { sf_flo = res.a_lo; sf_fhi = res.a_hi; sf_fb = sf_flo > sf_fhi; }
-                if(!sf_rb) { sf_rlo = res.b_lo; sf_rhi = res.b_hi; sf_rb = sf_rlo > sf_rhi; }
-                ++sf_t;
+                if(!m_fb) { m_flo = res.a_lo; m_fhi = res.a_hi; m_fb = m_flo > m_fhi; }
+                if(!m_rb) { m_rlo = res.b_lo; m_rhi = res.b_hi; m_rb = m_rlo > m_rhi; }
+                ++m_t;
             }
         } else {
-            sf_flo = res.a_lo; sf_fhi = res.a_hi; sf_rlo = res.b_lo; sf_rhi = res.b_hi;
+            m_flo = res.a_lo; m_fhi = res.a_hi; m_rlo = res.b_lo; m_rhi = res.b_hi;
             sf_store_leaf();
-            ++sf_j;
+            ++m_j;
         }
         sf_advance();
     }
@@ -442,7 +532,7 @@ struct ReadSM {
         uint64_t totalcount = 0;
         int maxfreqsofleave = 0;
         for(uint32_t b = 0; b < 4; ++b) {
-            freq[b] = (int)(isize(ex_flo[b], ex_fhi[b]) + isize(ex_rlo[b], ex_rhi[b]));
+            freq[b] = (int)(isize(exv(b, 0), exv(b, 1)) + isize(exv(b, 2), exv(b, 3)));
             totalcount += (uint64_t)(int64_t)freq[b];
             if(freq[b] > maxfreqsofleave) maxfreqsofleave = freq[b];
         }
@@ -453,7 +543,7 @@ struct ReadSM {
             const double kmerRatioNotPass = 2;
             double kmerRatioCutoff = 0;
             const double kmerRatio = (double)kmerFreq / (double)maxfreqsofleave;
-            const bool efv = ex_flo[b] <= ex_fhi[b], erv = ex_rlo[b] <= ex_rhi[b];
+            const bool efv = exv(b, 0) <= exv(b, 1), erv = exv(b, 2) <= exv(b, 3);
             const uint32_t code5 = (uint32_t)(((lf.suf_lo << 2) | b) & 0x3FFu);
             const bool isMatchedBy5mer = ismatchedbykmer(code5, efv, erv);
             const bool isFreqPass = kmerFreq >= IntervalSizeCutoff;
@@ -606,7 +696,7 @@ struct ReadSM {
         WalkResultRec& rr = results()[lf.res_first - 1];
         rr.error_rate = lf.globalErr;
         rr.match_i = (uint32_t)hit;
-        uint32_t* dst = rpaths() + (uint64_t)(lf.res_first - 1) * rw.pathw;
+        uint32_t* dst = rpaths() + (uint64_t)(lf.res_first - 1) * pathw;
         const uint32_t nw = (plen + 15) >> 4;
         for(uint32_t kk = 0; kk < nw; ++kk) dst[kk] = pw[kk];
         uint32_t len = plen;
@@ -635,7 +725,6 @@ struct ReadSM {
                 nextp[j] = head[hb];
                 head[hb] = (uint16_t)j;
             }
-            if(strand) n9r = n; else n9f = n;
         }
         uint16_t* h5 = head5(); uint16_t* n5p = next5(); const uint8_t* f5 = flags5();
         for(uint32_t c = 0; c < 1024; ++c) h5[c] = 0xFFFFu;
@@ -697,32 +786,21 @@ struct ReadSM {
         att_i = 0;
         pc = PC_ATT_LEAF;
     }
-    // first request of leaf att_i's getFMIndexExtensions (or the end of attempToExtend)
+    // the one request of leaf att_i's getFMIndexExtensions (or the end of attempToExtend)
     LRSC_SM void att_leaf()
     {
         if(att_i >= n_cur) { pc = PC_ATT_DONE; return; }
-        att_b = 0;
-        pc = PC_EXT;
-        ext_issue();
-    }
-    LRSC_SM void ext_issue()
-    {
         const LeafT& lf = cur()[att_i];
         const bool fv = lf.flo <= lf.fhi, rv = lf.rlo <= lf.rhi;
-        req_rank(lf.flo, lf.fhi, att_b, fv, lf.rlo, lf.rhi, 3u - att_b, rv, false);
+        req.kind = kReqExt;
+        req.flags = (fv ? kReqDoA : 0u) | (rv ? kReqDoB : 0u);
+        req.a_lo = lf.flo; req.a_hi = lf.fhi; req.b_lo = lf.rlo; req.b_hi = lf.rhi;
+        pc = PC_EXT;
     }
-    LRSC_SM void ext_result(const SmReq<P>& res)
+    // all four extension pairs of leaf att_i are in ex: the acceptance ladder, at most twice (second time with the threshold
+    // lowered by one, only for the best leaf of a multi-leaf frontier: .cpp:403-421), then updateLeaves (:468-488)
+    LRSC_SM void ext_eval()
     {
-        const uint32_t b = att_b;
-        // results land in statically indexed slots
-        if(b == 0) { ex_flo[0] = res.a_lo; ex_fhi[0] = res.a_hi; ex_rlo[0] = res.b_lo; ex_rhi[0] = res.b_hi; }
-        else if(b == 1) { ex_flo[1] = res.a_lo; ex_fhi[1] = res.a_hi; ex_rlo[1] = res.b_lo; ex_rhi[1] = res.b_hi; }
-        else if(b == 2) { ex_flo[2] = res.a_lo; ex_fhi[2] = res.a_hi; ex_rlo[2] = res.b_lo; ex_rhi[2] = res.b_hi; }
-        else { ex_flo[3] = res.a_lo; ex_fhi[3] = res.a_hi; ex_rlo[3] = res.b_lo; ex_rhi[3] = res.b_hi; }
-        ++att_b;
-        if(att_b < 4) { ext_issue(); return; }
-        // all four pairs known: the acceptance ladder, at most twice (second time with the threshold lowered by one,
-        // only for the best leaf of a multi-leaf frontier: .cpp:403-421)
         LeafT* cu = cur();
         const LeafT& par = cu[att_i];
         int freq[4];
@@ -735,7 +813,7 @@ struct ReadSM {
             min_SA_threshold--;
             count++;
         }
-        min_SA_threshold += (uint64_t)count;
+        min_SA_threshold += (uint32_t)count;
         if(mask != 0) {
             LeafT* nx = nxt();
             for(uint32_t bb = 0; bb < 4; ++bb) {
@@ -743,7 +821,7 @@ struct ReadSM {
                 if(n_nxt >= kMaxChildren) { error = LRSC_WALK_ERR_CHILDREN; pc = PC_WALK_END; return; }
                 LeafT& ch = nx[n_nxt++];
                 ch = par;                                          // createChild copies the node state (SAINode.cpp:166-189)
-                ch.flo = ex_flo[bb]; ch.fhi = ex_fhi[bb]; ch.rlo = ex_rlo[bb]; ch.rhi = ex_rhi[bb];
+                ch.flo = exv(bb, 0); ch.fhi = exv(bb, 1); ch.rlo = exv(bb, 2); ch.rhi = exv(bb, 3);
                 ch.kmerFrequency = freq[bb];
                 ch.currOverlapLen++;
                 ch.queryOverlapLen++;
@@ -797,7 +875,6 @@ struct ReadSM {
     {
         PrunedBySeedSupport();
         LeafT* nx = nxt(); LeafT* cu = cur();
-        const uint32_t pathw = rw.pathw;
         uint32_t survivors = 0;
         for(uint32_t c = 0; c < n_nxt; ++c) survivors += nx[c].alive;
         ++steps;
@@ -874,7 +951,7 @@ struct ReadSM {
             if(bestI < 0) return -4;
             *out_len_ = rs[bestI].path_len;
             *out_match_i = rs[bestI].match_i;
-            const uint32_t* src = rpaths() + (uint64_t)bestI * rw.pathw;
+            const uint32_t* src = rpaths() + (uint64_t)bestI * pathw;
             const uint32_t nw = (rs[bestI].path_len + 15) >> 4;
             for(uint32_t kk = 0; kk < nw; ++kk) out_words[kk] = src[kk];
             return 1;
@@ -891,75 +968,143 @@ struct ReadSM {
     // =========================================================================================================
     LRSC_SM void prep_emit()
     {
-        const uint32_t i = prep_i, s = prep_s;
-        const bool fval = prep_flo <= prep_fhi, rval = prep_rlo <= prep_rhi;
+        const uint32_t i = m_j, s = m_t;
+        const bool fval = m_flo <= m_fhi, rval = m_rlo <= m_rhi;
         if(s == 5) flags5()[i] = (uint8_t)((fval ? 1 : 0) | (rval ? 2 : 0));
         if(s == seedSize()) {
             SortItem* a = it9f() + i; SortItem* b = it9r() + i;
-            a->key = fval ? (uint64_t)prep_flo : kNoKey; a->val = i; a->pad = 0;
-            b->key = rval ? (uint64_t)prep_rlo : kNoKey; b->val = i; b->pad = 0;
+            a->key = fval ? (uint64_t)m_flo : kNoKey; a->val = i; a->pad = 0;
+            b->key = rval ? (uint64_t)m_rlo : kNoKey; b->val = i; b->pad = 0;
         }
-        if(s == minOverlap() && prep_term) {
+        if(s == minOverlap() && m_flag) {
             P* t = term() + (uint64_t)(i - (uint32_t)(k + interval)) * 4;
-            t[0] = prep_flo; t[1] = prep_fhi; t[2] = prep_rlo; t[3] = prep_rhi;
+            t[0] = m_flo; t[1] = m_fhi; t[2] = m_rlo; t[3] = m_rhi;
         }
+    }
+    // table index holding exactly k-mers of size kk (-1: none)
+    LRSC_SM int table_of(uint32_t kk) const
+    {
+        const int t = best_table(kk);
+        return (t >= 0 && table_k(t) == kk) ? t : -1;
+    }
+    // one entry of table t: {fwd.lo, fwd.hi, rvc.lo, rvc.hi}
+    LRSC_SM void table_entry(int t, uint32_t code, P e[4]) const
+    {
+        const void* tabv = t == 0 ? fm->ktab[0].entries : t == 1 ? fm->ktab[1].entries : t == 2 ? fm->ktab[2].entries
+                         : t == 3 ? fm->ktab[3].entries : fm->ktab[4].entries;
+        if(WIDE) {
+            const uint4* tp = reinterpret_cast<const uint4*>(tabv) + (uint64_t)code * 2;
+            const uint4 a = tp[0], b = tp[1];
+            e[0] = (P)(((uint64_t)a.y << 32) | a.x); e[1] = (P)(((uint64_t)a.w << 32) | a.z);
+            e[2] = (P)(((uint64_t)b.y << 32) | b.x); e[3] = (P)(((uint64_t)b.w << 32) | b.z);
+        } else {
+            const uint4 a = reinterpret_cast<const uint4*>(tabv)[code];
+            e[0] = (P)a.x; e[1] = (P)a.y; e[2] = (P)a.z; e[3] = (P)a.w;
+        }
+    }
+    // PREP when tables of exactly the three sizes exist (the normal configuration: 5, idmer = 9, minOverlap = 13): every emit
+    // of an offset is one table entry, nothing chains, so kPrepBatch offsets are answered per sweep with all look-ups in flight.
+    static constexpr uint32_t kPrepBatch = 4;
+    LRSC_SM bool prep_fast()
+    {
+        const uint32_t seedk = seedSize(), mink = minOverlap();
+        if(seedk <= 5 || mink <= seedk) return false;
+        const int t5 = table_of(5), t9 = table_of(seedk), t13 = table_of(mink);
+        if(t5 < 0 || t9 < 0 || t13 < 0) return false;
+        const uint8_t* qq = q();
+        const uint32_t trg0 = (uint32_t)(k + interval);
+        P e5[kPrepBatch][4], e9[kPrepBatch][4], e13[kPrepBatch][4];
+        bool d5[kPrepBatch], d9[kPrepBatch], d13[kPrepBatch];
+        for(uint32_t u = 0; u < kPrepBatch; ++u) {
+            const uint32_t i = m_j + u;
+            d5[u] = i + 5 <= Lq; d9[u] = i + seedk <= Lq; d13[u] = i >= trg0 && i + mink <= Lq;
+            uint32_t code = 0;
+            const uint32_t kk = d13[u] ? mink : d9[u] ? seedk : d5[u] ? 5u : 0u;
+            uint32_t c5 = 0, c9 = 0;
+            for(uint32_t t = 0; t < kk; ++t) {
+                code = (code << 2) | qq[i + t];
+                if(t == 4) c5 = code;
+                if(t + 1 == seedk) c9 = code;
+            }
+            if(d5[u]) table_entry(t5, c5, e5[u]);
+            if(d9[u]) table_entry(t9, c9, e9[u]);
+            if(d13[u]) table_entry(t13, code, e13[u]);
+        }
+        for(uint32_t u = 0; u < kPrepBatch; ++u) {
+            const uint32_t i = m_j + u;
+            if(d5[u]) flags5()[i] = (uint8_t)((e5[u][0] <= e5[u][1] ? 1 : 0) | (e5[u][2] <= e5[u][3] ? 2 : 0));
+            if(d9[u]) {
+                SortItem* a = it9f() + i; SortItem* b = it9r() + i;
+                a->key = e9[u][0] <= e9[u][1] ? (uint64_t)e9[u][0] : kNoKey; a->val = i; a->pad = 0;
+                b->key = e9[u][2] <= e9[u][3] ? (uint64_t)e9[u][2] : kNoKey; b->val = i; b->pad = 0;
+            }
+            if(d13[u]) {
+                P* t = term() + (uint64_t)(i - trg0) * 4;
+                t[0] = e13[u][0]; t[1] = e13[u][1]; t[2] = e13[u][2]; t[3] = e13[u][3];
+            }
+            n_tab += (d5[u] ? 1u : 0u) + (d9[u] ? 1u : 0u) + (d13[u] ? 1u : 0u);
+        }
+        m_j += kPrepBatch;
+        if(m_j >= Lq) pc = PC_BEGIN;
+        return true;
     }
     LRSC_SM void prep_advance()
     {
+        if(prep_fast()) return;
         const uint32_t seedk = seedSize(), mink = minOverlap();
         const uint8_t* qq = q();
         const uint32_t trg0 = (uint32_t)(k + interval);
         while(true) {
-            if(prep_start) {
-                if(prep_i >= Lq) { pc = PC_BEGIN; return; }
-                const uint32_t i = prep_i;
-                prep_term = i >= trg0 && i + mink <= Lq;
+            if(m_start) {
+                if(m_j >= Lq) { pc = PC_BEGIN; return; }
+                const uint32_t i = m_j;
+                m_flag = i >= trg0 && i + mink <= Lq;
                 uint32_t kmax = 0;
                 if(i + 5 <= Lq) kmax = 5;
                 if(i + seedk <= Lq) kmax = seedk;
-                if(prep_term) kmax = mink > kmax ? mink : kmax;
-                prep_kmax = kmax;
-                prep_s = 0; prep_fb = false; prep_rb = false;
-                prep_flo = prep_fhi = prep_rlo = prep_rhi = 0;
-                prep_start = false;
+                if(m_flag) kmax = mink > kmax ? mink : kmax;
+                m_len = kmax;
+                m_t = 0; m_fb = false; m_rb = false;
+                m_flo = m_fhi = m_rlo = m_rhi = 0;
+                m_start = false;
             }
-            if(prep_s >= prep_kmax) { ++prep_i; prep_start = true; continue; }
-            const uint32_t s = prep_s;
+            if(m_t >= m_len) { ++m_j; m_start = true; continue; }
+            const uint32_t s = m_t;
             const uint32_t next_emit = s < 5 ? 5u : s < seedk ? seedk : mink;
-            if(next_emit <= prep_kmax) {
+            if(next_emit <= m_len) {
                 const int tb = best_table(next_emit);
                 if(tb >= 0 && table_k(tb) == next_emit) {
                     uint32_t code = 0;
-                    for(uint32_t t = 0; t < next_emit; ++t) code = (code << 2) | qq[prep_i + t];
-                    prep_s = next_emit | 0x80000000u;
+                    for(uint32_t t = 0; t < next_emit; ++t) code = (code << 2) | qq[m_j + t];
+                    m_t = next_emit | 0x80000000u;
                     req_tab((uint32_t)tb, code);
                     return;
                 }
             }
-            const uint32_t c = qq[prep_i + s];
+            const uint32_t c = qq[m_j + s];
             if(s == 0) {
-                const IvT<P> f = init_interval<P>(sF, c), rr = init_interval<P>(sR, 3u - c);
-                prep_flo = f.lo; prep_fhi = f.hi; prep_rlo = rr.lo; prep_rhi = rr.hi;
-                prep_s = 1;
+                const IvT<P> f = init_interval<P>(sF(), c), rr = init_interval<P>(sR(), 3u - c);
+                m_flo = f.lo; m_fhi = f.hi; m_rlo = rr.lo; m_rhi = rr.hi;
+                m_t = 1;
                 n_rank += 2;
                 prep_emit();
                 continue;
             }
-            if(prep_fb && prep_rb) { ++prep_s; prep_emit(); continue; }     // both strands dead: nothing can change any more
-            req_rank(prep_flo, prep_fhi, c, !prep_fb, prep_rlo, prep_rhi, 3u - c, !prep_rb, false);
+            if(m_fb && m_rb) { ++m_t; prep_emit(); continue; }     // both strands dead: nothing can change any more
+            req_rank(m_flo, m_fhi, c, !m_fb, m_rlo, m_rhi, 3u - c, !m_rb, false);
             return;
         }
     }
     LRSC_SM void prep_result(const SmReq<P>& res)
     {
-        if(prep_s & 0x80000000u) {
-            prep_s &= 0x7FFFFFFFu;
-            prep_flo = res.a_lo; prep_fhi = res.a_hi; prep_rlo = res.b_lo; prep_rhi = res.b_hi;
-            prep_fb = prep_flo > prep_fhi; prep_rb = prep_rlo > prep_rhi;
+        if(m_t & 0x80000000u) {
+            m_t &= 0x7FFFFFFFu;
+            m_flo = res.a_lo; m_fhi = res.a_hi; m_rlo = res.b_lo; m_rhi = res.b_hi;
+            m_fb = m_flo > m_fhi; m_rb = m_rlo > m_rhi;
         } else {
-            if(!prep_fb) { prep_flo = res.a_lo; prep_fhi = res.a_hi; prep_fb = prep_flo > prep_fhi; }
-            if(!prep_rb) { prep_rlo = res.b_lo; prep_rhi = res.b_hi; prep_rb = prep_rlo > prep_rhi; }
-            ++prep_s;
+            if(!m_fb) { m_flo = res.a_lo; m_fhi = res.a_hi; m_fb = m_flo > m_fhi; }
+            if(!m_rb) { m_rlo = res.b_lo; m_rhi = res.b_hi; m_rb = m_rlo > m_rhi; }
+            ++m_t;
         }
         prep_emit();
         prep_advance();
@@ -974,39 +1119,38 @@ struct ReadSM {
     }
 
     // set up at kernel start (fresh read, or a read that yielded / was parked in an earlier launch)
-    LRSC_SM void init(const FmIndexDev* fm_, const CorrectArgs* a_, uint32_t read_index)
+    LRSC_SM void init(const FmIndexDev* fm_, const CorrectArgs* a_, const StrandC<P>* sF_, const StrandC<P>* sR_, uint32_t read_index,
+                      P* ex_, uint32_t ex_stride_)
     {
-        fm = fm_; A = a_; r = read_index;
-        sF = strand_consts<P>(fm->strand[LRSC_RBWT]);
-        sR = strand_consts<P>(fm->strand[LRSC_BWT]);
-        rw = A->work[r];
+        fm = fm_; A = a_; sFp = sF_; sRp = sR_; r = read_index; ex = ex_; ex_stride = ex_stride_;
+        const ReadWork& rw = A->work[r];
         ReadOut& R = A->out[r];
-        const uint64_t rs = A->read_off[r];
-        rlen = (uint32_t)(A->read_off[r + 1] - rs);
-        read = A->codes + rs;
+        rs = A->read_off[r];
         n_seeds = A->seed_count[r];
-        seeds = A->seeds + seed_slab(rs, r, A->min_k) * kSeedInts;
-        out = A->out_codes + rw.out_off;
-        piece_start = A->piece_start + rw.piece_off;
+        lq_max = rw.lq_max; pathw = rw.pathw;
         ws = A->workspace + rw.ws_off;
+        const uint8_t* read = this->read();
+        const int32_t* seeds = this->seeds();
+        uint8_t* out = this->out();
+        uint32_t* piece_start = this->piece_start();
         req.kind = kReqNone;
         n_rank = 0; n_blk = 0; n_tab = 0;
         error = 0; state = kReadDone; walks_here = 0; next = 0; firstType = 0;
-        correctedLen = 0; totalWalkNum = 0; highErrorNum = 0; exceedDepthNum = 0; exceedLeaveNum = 0; FMNum = 0; DPNum = 0; seedDis = 0;
         out_len = 0; n_pieces = 0; steps = 0;
         S_seedLen = 0; S_end = 0; S_endBest = 0; S_maxFixed = 0; S_isRepeat = false; it = 1;
         const bool resume = A->resume != 0;
         if(resume) {
-            correctedLen = R.c[1]; totalWalkNum = R.c[3]; highErrorNum = R.c[4]; exceedDepthNum = R.c[5]; exceedLeaveNum = R.c[6];
-            FMNum = R.c[7]; DPNum = R.c[8]; seedDis = R.c[9];
-            out_len = R.out_len; n_pieces = R.n_pieces; steps = R.steps;
-        } else { R.cyc[0] = 0; R.cyc[1] = 0; R.cyc[2] = 0; R.cyc[3] = 0; R.steps = 0; }
+            out_len = R.out_len; n_pieces = R.n_pieces; steps = (uint32_t)R.steps;
+        } else {
+            for(int j = 0; j < 10; ++j) R.c[j] = 0;
+            R.cyc[0] = 0; R.cyc[1] = 0; R.cyc[2] = 0; R.cyc[3] = 0; R.steps = 0;
+        }
         steps0 = steps;
         if(!(n_seeds >= 2) || (resume && R.state == kReadDone)) { pc = PC_FINAL; return; }
         if(!resume) {
             // pieceVec.push_back(seedVec[0])
             piece_start[n_pieces++] = 0;
-            for(int t = 0; t < seeds[1]; ++t) out[out_len++] = read[seeds[0] + t];
+            copy_codes(out + out_len, read + seeds[0], (uint32_t)seeds[1]); out_len += (uint32_t)seeds[1];
             S_seedLen = seeds[1];
             load_source(seeds);
             it = 1;
@@ -1024,31 +1168,31 @@ struct ReadSM {
                     if(m.cons_len < R.dp_k) error = LRSC_WALK_ERR_DP;              // out.erase(0, k) would throw in the reference
                     else {
                         const uint32_t appended = m.cons_len - R.dp_k;
-                        if(out_len + appended > rw.out_cap) error = LRSC_WALK_ERR_OUTPUT;
+                        if(out_len + appended > out_cap()) error = LRSC_WALK_ERR_OUTPUT;
                         else {
-                            for(uint32_t j = 0; j < appended; ++j) out[out_len + j] = cons[R.dp_k + j];
+                            copy_codes(out + out_len, cons + R.dp_k, appended);
                             out_len += appended;
-                            correctedLen += appended;
-                            seedDis += T0[0] - S_end - 1;
-                            DPNum++;
+                            ctr(1) += appended;
+                            ctr(9) += T0[0] - S_end - 1;
+                            ctr(8)++;
                             S_seedLen += (int)appended;
                         }
                     }
                 } else if(A->split) {
-                    if(out_len + (uint32_t)T0[1] > rw.out_cap) error = LRSC_WALK_ERR_OUTPUT;
+                    if(out_len + (uint32_t)T0[1] > out_cap()) error = LRSC_WALK_ERR_OUTPUT;
                     else {
                         piece_start[n_pieces++] = out_len;
-                        for(int t = 0; t < T0[1]; ++t) out[out_len++] = read[T0[0] + t];
+                        { copy_codes(out + out_len, read + T0[0], (uint32_t)T0[1]); out_len += (uint32_t)T0[1]; }
                         S_seedLen = T0[1];
-                        correctedLen += T0[1];
+                        ctr(1) += T0[1];
                     }
                 } else {
                     const int raw = (T0[0] + T0[1] - 1) - S_end;
-                    if(out_len + (uint32_t)raw > rw.out_cap) error = LRSC_WALK_ERR_OUTPUT;
+                    if(out_len + (uint32_t)raw > out_cap()) error = LRSC_WALK_ERR_OUTPUT;
                     else {
-                        for(int t = 0; t < raw; ++t) out[out_len++] = read[S_end + 1 + t];
+                        { copy_codes(out + out_len, read + S_end + 1, (uint32_t)raw); out_len += (uint32_t)raw; }
                         S_seedLen += raw;
-                        correctedLen += T0[1];
+                        ctr(1) += T0[1];
                     }
                 }
                 load_source(T0);
@@ -1065,11 +1209,14 @@ struct ReadSM {
     LRSC_SM void next_walk(bool setup_now)
     {
         if(!(it < n_seeds) || error) { pc = PC_FINAL; return; }
-        if(next == 0 && A->max_walks != 0 && (walks_here >= A->max_walks || steps - steps0 >= (uint64_t)A->max_steps)) {
+        if(next == 0 && A->max_walks != 0 && (walks_here >= A->max_walks || steps - steps0 >= A->max_steps)) {
             state = kReadYield; pc = PC_FINAL; return;
         }
         if(!setup_now) return;
         ++walks_here;
+        const uint8_t* read = this->read();
+        const int32_t* seeds = this->seeds();
+        const uint8_t* out = this->out();
         const int32_t* T = seeds + (uint64_t)(it + (uint32_t)next) * kSeedInts;
         T_start = T[0]; T_len = T[1];
         T_isRepeat = (T[3] & 1) != 0;
@@ -1082,19 +1229,19 @@ struct ReadSM {
         rtou = S_isRepeat && !T_isRepeat;
         trg_len = rtou ? k : T_len;
         if(k < (int)A->seed_size || k > (int)kMaxInitK || k > S_seedLen || interval < 0 || trg_len < (int)A->min_overlap ||
-           (uint32_t)(k + interval + trg_len) > rw.lq_max) { error = LRSC_WALK_ERR_GEOMETRY; pc = PC_FINAL; return; }
+           (uint32_t)(k + interval + trg_len) > lq_max) { error = LRSC_WALK_ERR_GEOMETRY; pc = PC_FINAL; return; }
         Lq = (uint32_t)(k + interval + trg_len);
         uint8_t* qq = q();
         const uint8_t* tail = out + out_len - k;                           // source.seedStr.substr(seedLen - k)
         if(!rtou) {
-            for(int t = 0; t < k; ++t) qq[t] = tail[t];
-            for(int t = 0; t < interval; ++t) qq[k + t] = read[S_end + 1 + t];
-            for(int t = 0; t < T_len; ++t) qq[k + interval + t] = read[T_start + t];
+            copy_codes(qq, tail, (uint32_t)k);
+            copy_codes(qq + k, read + S_end + 1, (uint32_t)interval);
+            copy_codes(qq + k + interval, read + T_start, (uint32_t)T_len);
         } else {
             // src <-> trg swapped and everything reverse-complemented (:176-184)
-            for(int t = 0; t < k; ++t) qq[t] = (uint8_t)(3 - read[T_start + k - 1 - t]);
-            for(int t = 0; t < interval; ++t) qq[k + t] = (uint8_t)(3 - read[S_end + interval - t]);
-            for(int t = 0; t < k; ++t) qq[k + interval + t] = (uint8_t)(3 - tail[k - 1 - t]);
+            copy_codes_rc(qq, read + T_start + k - 1, (uint32_t)k);
+            copy_codes_rc(qq + k, read + S_end + interval, (uint32_t)interval);
+            copy_codes_rc(qq + k + interval, tail + k - 1, (uint32_t)k);
         }
         initk = (uint32_t)k;
         maxOverlap = (uint32_t)k + 2;
@@ -1103,7 +1250,7 @@ struct ReadSM {
         if(interval > 100) maxIndelSize = (uint64_t)(interval * 0.2); else maxIndelSize = 20;
         maxLength = (uint64_t)((1.2 * (interval + 10)) + (double)(2 * (uint64_t)k));
         minLength = (uint64_t)((0.8 * (interval - 20)) + (double)(2 * (uint64_t)k));
-        prep_i = 0; prep_start = true;
+        m_j = 0; m_start = true;
         pc = PC_PREP;
     }
 
@@ -1115,6 +1262,10 @@ struct ReadSM {
         const int code = finish_walk(&plen, bestw, &mi);
         if(code <= LRSC_WALK_ERR_CHILDREN) { error = code; pc = PC_FINAL; return; }
         if(next == 0) firstType = code;
+        const uint8_t* read = this->read();
+        const int32_t* seeds = this->seeds();
+        uint8_t* out = this->out();
+        uint32_t* piece_start = this->piece_start();
         const int32_t* T = seeds + (uint64_t)(it + (uint32_t)next) * kSeedInts;
         const uint8_t* qq = q();
         if(code > 0) {
@@ -1125,29 +1276,31 @@ struct ReadSM {
             uint32_t appended = 0;
             if(!rtou) {
                 appended = M - (uint32_t)k;
-                if(out_len + appended > rw.out_cap) { error = LRSC_WALK_ERR_OUTPUT; pc = PC_FINAL; return; }
-                for(uint32_t j = (uint32_t)k; j < M; ++j)
-                    out[out_len + j - k] = (uint8_t)(j < plen ? path_get(bestw, j) : qq[k + interval + tail_from + (j - plen)]);
+                if(out_len + appended > out_cap()) { error = LRSC_WALK_ERR_OUTPUT; pc = PC_FINAL; return; }
+                // merged[k .. M): the path from character k on, then the rest of the target
+                uint8_t* d = out + out_len;
+                const uint32_t from_path = plen > (uint32_t)k ? plen - (uint32_t)k : 0u;
+                unpack_path(d, bestw, (uint32_t)k, from_path);
+                copy_codes(d + from_path, qq + k + interval + tail_from + ((uint32_t)k > plen ? (uint32_t)k - plen : 0u), appended - from_path);
             } else {
                 // revcomp(merged) + target.substr(k), minus the first k characters (:195-200)
                 const uint32_t total = M + (uint32_t)(T_len - k);
                 appended = total - (uint32_t)k;
-                if(out_len + appended > rw.out_cap) { error = LRSC_WALK_ERR_OUTPUT; pc = PC_FINAL; return; }
-                for(uint32_t j = (uint32_t)k; j < total; ++j) {
-                    uint8_t c;
-                    if(j < M) {
-                        const uint32_t m = M - 1 - j;
-                        c = (uint8_t)(3 - (m < plen ? path_get(bestw, m) : qq[k + interval + tail_from + (m - plen)]));
-                    } else
-                        c = read[T_start + k + (j - M)];
-                    out[out_len + j - k] = c;
-                }
+                if(out_len + appended > out_cap()) { error = LRSC_WALK_ERR_OUTPUT; pc = PC_FINAL; return; }
+                uint8_t* d = out + out_len;
+                // j = k .. M-1 reads merged[m], m = M-1-j = M-1-k .. 0: first the target tail backwards (m >= plen), then the path backwards
+                const uint32_t n_rc = M > (uint32_t)k ? M - (uint32_t)k : 0u;
+                const uint32_t m_first = M - 1u - (uint32_t)k;                                  // valid when n_rc > 0
+                const uint32_t n_tail = n_rc == 0 ? 0u : (m_first >= plen ? (m_first - plen + 1u < n_rc ? m_first - plen + 1u : n_rc) : 0u);
+                if(n_tail) copy_codes_rc(d, qq + k + interval + tail_from + (m_first - plen), n_tail);
+                if(n_rc > n_tail) unpack_path_rc(d + n_tail, bestw, m_first - n_tail, n_rc - n_tail);
+                copy_codes(d + n_rc, read + T_start + k, total - M);
             }
             out_len += appended;
-            correctedLen += appended;
-            seedDis += interval;
-            FMNum++;
-            totalWalkNum++;
+            ctr(1) += appended;
+            ctr(9) += interval;
+            ctr(7)++;
+            ctr(3)++;
             S_seedLen += (int)appended;                                      // SeedFeature::append
             S_end = T_start + T_len - 1; S_endBest = T[5]; S_isRepeat = T_isRepeat; S_maxFixed = T[2];
             it += (uint32_t)next + 1;
@@ -1157,13 +1310,13 @@ struct ReadSM {
         }
         if(next + 1 < A->next_target && it + (uint32_t)next + 1 < n_seeds) { next++; pc = PC_NEXT; return; }
         switch(firstType) {
-            case -1: highErrorNum++; break;
-            case -2: exceedDepthNum++; break;
-            case -3: exceedLeaveNum++; break;
+            case -1: ctr(4)++; break;
+            case -2: ctr(5)++; break;
+            case -3: ctr(6)++; break;
             default: error = LRSC_WALK_ERR_CODE; break;
         }
         if(error) { pc = PC_FINAL; return; }
-        totalWalkNum++;
+        ctr(3)++;
         const int32_t* T0 = seeds + (uint64_t)it * kSeedInts;               // target = *iterTarget
         if(!A->no_dp) {
             // correctByMSAlignment (:208-236): park the read with its query = src k-mer + raw segment + target seed
@@ -1174,12 +1327,12 @@ struct ReadSM {
                 k0 = S_seedLen < T0[1] ? S_seedLen : T0[1];
                 k0 = k0 < A->start_kmer_len + 2 ? k0 : A->start_kmer_len + 2;
             }
-            if(k0 < 1 || k0 > S_seedLen || k0 > T0[1] || iv0 < 0 || (uint32_t)(k0 + iv0 + T0[1]) > rw.lq_max) { error = LRSC_WALK_ERR_GEOMETRY; pc = PC_FINAL; return; }
+            if(k0 < 1 || k0 > S_seedLen || k0 > T0[1] || iv0 < 0 || (uint32_t)(k0 + iv0 + T0[1]) > lq_max) { error = LRSC_WALK_ERR_GEOMETRY; pc = PC_FINAL; return; }
             uint8_t* dq = dpq();
             const uint8_t* tl = out + out_len - k0;
-            for(int t = 0; t < k0; ++t) dq[t] = tl[t];
-            for(int t = 0; t < iv0; ++t) dq[k0 + t] = read[S_end + 1 + t];
-            for(int t = 0; t < T0[1]; ++t) dq[k0 + iv0 + t] = read[T0[0] + t];
+            copy_codes(dq, tl, (uint32_t)k0);
+            copy_codes(dq + k0, read + S_end + 1, (uint32_t)iv0);
+            copy_codes(dq + k0 + iv0, read + T0[0], (uint32_t)T0[1]);
             R.dp_k = (uint32_t)k0; R.dp_lq = (uint32_t)(k0 + iv0 + T0[1]);
             R.dp_total_freq = (int64_t)S_maxFixed + (int64_t)T0[2];
             state = kReadParked;
@@ -1187,17 +1340,17 @@ struct ReadSM {
             return;
         }
         if(A->split) {
-            if(out_len + (uint32_t)T0[1] > rw.out_cap) { error = LRSC_WALK_ERR_OUTPUT; pc = PC_FINAL; return; }
+            if(out_len + (uint32_t)T0[1] > out_cap()) { error = LRSC_WALK_ERR_OUTPUT; pc = PC_FINAL; return; }
             piece_start[n_pieces++] = out_len;                               // pieceVec.push_back(target)
-            for(int t = 0; t < T0[1]; ++t) out[out_len++] = read[T0[0] + t];
+            { copy_codes(out + out_len, read + T0[0], (uint32_t)T0[1]); out_len += (uint32_t)T0[1]; }
             S_seedLen = T0[1];
         } else {
             const int raw = (T0[0] + T0[1] - 1) - S_end;                     // readSeq.substr(source.seedEndPos + 1, ...)
-            if(out_len + (uint32_t)raw > rw.out_cap) { error = LRSC_WALK_ERR_OUTPUT; pc = PC_FINAL; return; }
-            for(int t = 0; t < raw; ++t) out[out_len++] = read[S_end + 1 + t];
+            if(out_len + (uint32_t)raw > out_cap()) { error = LRSC_WALK_ERR_OUTPUT; pc = PC_FINAL; return; }
+            { copy_codes(out + out_len, read + S_end + 1, (uint32_t)raw); out_len += (uint32_t)raw; }
             S_seedLen += raw;
         }
-        correctedLen += T0[1];
+        ctr(1) += T0[1];
         load_source(T0);
         it += 1;
         next = 0;
@@ -1210,8 +1363,7 @@ struct ReadSM {
         R.steps = steps;
         R.it = it; R.s_seed_len = S_seedLen; R.s_end = S_end; R.s_end_best = S_endBest; R.s_max_fixed = S_maxFixed;
         R.s_is_repeat = S_isRepeat ? 1 : 0;
-        R.c[0] = rlen; R.c[1] = correctedLen; R.c[2] = n_seeds; R.c[3] = totalWalkNum; R.c[4] = highErrorNum;
-        R.c[5] = exceedDepthNum; R.c[6] = exceedLeaveNum; R.c[7] = FMNum; R.c[8] = DPNum; R.c[9] = seedDis;
+        R.c[0] = (int64_t)(A->read_off[r + 1] - rs); R.c[2] = n_seeds;
         R.n_pieces = n_pieces; R.out_len = out_len; R.merge = n_pieces != 0; R.error = error;
         R.state = error ? kReadDone : state;
         pc = PC_DONE;
@@ -1220,13 +1372,25 @@ struct ReadSM {
     // =========================================================================================================
     // one sweep: consume the answered request (if any), then run forward through the blocks until the next request
     // =========================================================================================================
-    LRSC_SM void sweep(bool have_result, const SmReq<P>& res, bool setup_now)
+    // lanes inside the extension loop of a walk (the population the step gate is a quorum of)
+    LRSC_SM bool in_walk() const { return (pc >= PC_FS && pc <= PC_STEP_ENTRY) || pc == PC_ATT_ENTRY || pc == PC_ATT_LEAF; }
+    // ... of which: waiting at the gate in front of the memory-heavy blocks (acceptance ladder + children, pruning + commit)
+    LRSC_SM bool at_gate() const { return pc == PC_EXT_READY || pc == PC_PRUNE; }
+    LRSC_SM bool in_prep() const { return pc == PC_PREP; }
+
+    // One sweep: consume the answered request (if any), then run forward through the blocks until the next request.
+    //   setup_now  the set-up quorum is met: lanes between walks build their next m_query and start PREP
+    //   begin_now  no lane of the wavefront is in PREP any more: lanes waiting with a finished PREP build their chains
+    //              (sort) and root together
+    //   gate_now   the step gate is open: lanes at the gate run the memory-heavy blocks together, so that their
+    //              dependent workspace accesses overlap instead of each lane paying its own latency in its own sweep
+    LRSC_SM void sweep(bool have_result, const SmReq<P>& res, bool setup_now, bool begin_now, bool gate_now)
     {
         req.kind = kReqNone;
         if(have_result) {
             if(pc == PC_FS) fs_result(res);
             else if(pc == PC_SF) sf_result_in(res);
-            else if(pc == PC_EXT) ext_result(res);
+            else if(pc == PC_EXT) pc = PC_EXT_READY;
             else if(pc == PC_PREP) prep_result(res);
         }
         if(pc == PC_ROOT_DONE) {
@@ -1234,16 +1398,17 @@ struct ReadSM {
             root.kmerFrequency = (int)(isize(root.flo, root.fhi) + isize(root.rlo, root.rhi));
             pc = PC_STEP_ENTRY;
         }
+        if(pc == PC_EXT_READY && gate_now) ext_eval();
         if(pc == PC_ATT_DONE) att_done();
         if(pc == PC_AFTER_SF_A) { att_no = 2; fs_begin(0, n_cur, (uint32_t)sf_result, PC_ATT_ENTRY, true); }
         if(pc == PC_POST) post();
         if(pc == PC_AFTER_SF_B) fs_begin(1, n_nxt, (uint32_t)sf_result, PC_PRUNE, true);
-        if(pc == PC_PRUNE) prune_and_commit();
+        if(pc == PC_PRUNE && gate_now) prune_and_commit();
         if(pc == PC_STEP_ENTRY) step_entry();
         if(pc == PC_WALK_END) walk_end();
         if(pc == PC_NEXT) next_walk(setup_now);
         if(pc == PC_PREP && req.kind == kReqNone) prep_advance();
-        if(pc == PC_BEGIN) begin_walk();
+        if(pc == PC_BEGIN && begin_now) begin_walk();
         if(pc == PC_ATT_ENTRY) att_entry();
         if(pc == PC_ATT_LEAF) att_leaf();
         if(pc == PC_FINAL) finalize();

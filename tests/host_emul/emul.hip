@@ -16,6 +16,12 @@
 
 using namespace lrsc;
 
+// debugging aid: per-sweep trace of one read (compare with the device kernel's LRSC_SM_TRACE file)
+static uint32_t* g_trace = nullptr;
+static uint32_t g_trace_cap = 0, g_trace_pos = 1, g_trace_read = 0;
+extern "C" void emul_set_trace(uint32_t* buf, uint32_t cap, uint32_t read) { g_trace = buf; g_trace_cap = cap; g_trace_pos = 1; g_trace_read = read; }
+extern "C" uint32_t emul_trace_words() { return g_trace_pos; }
+
 struct EmulIndex {
     StrandImage image[2];
     bool wide = false;
@@ -158,13 +164,15 @@ static int run_emul(EmulIndex* ix, const lrsc_params& p, const uint8_t* codes, c
         for(uint32_t r : todo) {
             ReadSM<WIDE> L;
             L.n_rank = L.n_blk = L.n_tab = 0;
-            L.init(&ix->dev, &a, r);
+            P ex[16];
+            L.init(&ix->dev, &a, &sF, &sR, r, ex, 1);
             SmReq<P> res{};
             uint64_t guard = 0;
             while(L.pc != PC_DONE) {
                 const bool have = L.req.kind != kReqNone;
-                if(have) { sm_answer<WIDE>(ix->dev, sF, sR, ix->mtab.data(), L.req, res, L.n_rank, L.n_blk, L.n_tab); ++requests; }
-                L.sweep(have, res, true);
+                if(have) { sm_answer<WIDE>(ix->dev, sF, sR, ix->mtab.data(), L.req, res, ex, 1, L.n_rank, L.n_blk, L.n_tab); ++requests; }
+                if(g_trace && launches == 1 && r == g_trace_read) sm_trace<P>(g_trace, g_trace_cap, g_trace_pos, L.pc, have, L.req, res);
+                L.sweep(have, res, true, true, true);
                 ++sweeps;
                 if(++guard > (1ull << 34)) return -2;
             }
