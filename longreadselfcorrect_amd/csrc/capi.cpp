@@ -1385,7 +1385,7 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
         if(const char* e = std::getenv("LRSC_CORRECT_OCC")) a.occupancy = std::atoi(e) >= 4 ? 4u : 2u;   // 8 (64 VGPRs) spills too much: 38 s vs 21 s at 100k reads
         {
             const char* ke = std::getenv("LRSC_CORRECT_KERNEL");
-            if(!(ke && std::strcmp(ke, "lane") == 0)) a.occupancy = 2;     // the state-machine kernel is built for 2 wavefronts per SIMD
+            if(ke && std::strcmp(ke, "sm") == 0) a.occupancy = 1;     // the state-machine kernel keeps its per-lane state in LDS: one wavefront per SIMD
         }
         const uint32_t resident = (uint32_t)cus * 4u * a.occupancy;
         a.reads_per_wave = 4;
@@ -1458,11 +1458,11 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
         x.queue_waves = std::max<uint32_t>(1, (x.n_reads + x.reads_per_wave * queue_rpl - 1) / (x.reads_per_wave * queue_rpl));
         return hipMemsetAsync(d_queue.p, 0, sizeof(uint32_t), ctx->stream);
     };
-    // LRSC_CORRECT_KERNEL=lane selects round 1's lane-per-read kernel with nested control flow (kept for A/B runs);
-    // the default is the wavefront-convergent state machine (correct_sm.hip), which reads its arguments from device memory:
-    // a ring of argument slots, one per launch
+    // LRSC_CORRECT_KERNEL=sm selects the wavefront-convergent state-machine kernel (correct_sm.hip; bit-identical, measured
+    // 48.6 vs 57.4 Mbases/s at 100k reads on the --nodp flow at the end of round 2: DESIGN.md section 4); the default stays the
+    // lane-per-read kernel of round 1
     const char* kern_env = std::getenv("LRSC_CORRECT_KERNEL");
-    const bool use_sm = !(kern_env && std::strcmp(kern_env, "lane") == 0);
+    const bool use_sm = kern_env && std::strcmp(kern_env, "sm") == 0;
     constexpr uint32_t kArgSlots = 16;
     DevBuf<CorrectArgs> d_args;
     DevBuf<FmIndexDev> d_fm;
@@ -1478,12 +1478,15 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
         CorrectArgs* slot = d_args.p + (arg_slot++ % kArgSlots);
         hipError_t e1 = hipMemcpyAsync(slot, &x, sizeof(CorrectArgs), hipMemcpyHostToDevice, s);
         if(e1 != hipSuccess) return e1;
-        return launch_correct_sm(d_fm.p, slot, x, ctx->fm.wide != 0, s);
+        return launch_correct_sm(d_fm.p, slot, x, ctx->fm.wide != 0, s, ctx->fm);
     };
     a.profile = std::getenv("LRSC_CORRECT_PROFILE") ? 1u : 0u;
     a.setup_quorum_pct = 40;
     if(const char* e = std::getenv("LRSC_CORRECT_QUORUM")) a.setup_quorum_pct = (uint32_t)std::min(100, std::max(0, std::atoi(e)));
     a.step_gate_pct = 75;
+    a.slow_gate_sweeps = 12;
+    if(const char* e = std::getenv("LRSC_CORRECT_SLOW_GATE")) a.slow_gate_sweeps = (uint32_t)std::max(1, std::atoi(e));
+    if(const char* e = std::getenv("LRSC_SM_DBG")) a.dbg_flags = (uint32_t)std::atoi(e);
     if(const char* e = std::getenv("LRSC_CORRECT_GATE")) a.step_gate_pct = (uint32_t)std::min(100, std::max(0, std::atoi(e)));
     a.max_walks = p.no_dp ? 0u : 64u;
     a.max_steps = 2000;
@@ -1504,8 +1507,8 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
     uint32_t prof_waves = 0;
     if(std::getenv("LRSC_SM_PROFILE") && use_sm) {
         prof_waves = (n + a.reads_per_wave - 1) / a.reads_per_wave;
-        HIP_TRY(d_prof.reserve((size_t)prof_waves * 16));
-        HIP_TRY(hipMemset(d_prof.p, 0, (size_t)prof_waves * 16 * 8));
+        HIP_TRY(d_prof.reserve((size_t)prof_waves * 32));
+        HIP_TRY(hipMemset(d_prof.p, 0, (size_t)prof_waves * 32 * 8));
         a.prof = d_prof.p;
     }
     HIP_TRY(with_queue(a));
@@ -1515,16 +1518,23 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
     // ---- DP rounds: reads whose FM-extension failed are parked with a correctByMSAlignment request; the DP stage
     //      answers all of them at once and the kernel resumes just those reads (:129-149) -------------------------------
     if(a.prof) {
-        std::vector<unsigned long long> pr((size_t)prof_waves * 16);
+        std::vector<unsigned long long> pr((size_t)prof_waves * 32);
         HIP_TRY(hipMemcpy(pr.data(), d_prof.p, pr.size() * 8, hipMemcpyDeviceToHost));
         double tot[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for(uint32_t w = 0; w < prof_waves; ++w) for(int j = 0; j < 9; ++j) tot[j] += (double)pr[(size_t)w * 16 + j];
+        for(uint32_t w = 0; w < prof_waves; ++w) for(int j = 0; j < 9; ++j) tot[j] += (double)pr[(size_t)w * 32 + j];
+        double blk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for(uint32_t w = 0; w < prof_waves; ++w) for(int j = 0; j < 12; ++j) blk[j] += (double)pr[(size_t)w * 32 + 16 + j];
         const double all = tot[0] + tot[1] + tot[2] + tot[3] + tot[4];
         std::fprintf(stderr, "[lrsc] sm kernel, %u waves, ticks per wave %.3g: R-phase %.1f%%; sweeps: begin %.1f%% (%.0f sweeps/wave, %.0f ticks each), "
                              "between-walks %.1f%% (%.0f, %.0f), step gate open %.1f%% (%.0f, %.0f), light %.1f%% (%.0f, %.0f)\n", prof_waves, all / prof_waves,
                      100 * tot[0] / all, 100 * tot[1] / all, tot[5] / prof_waves, tot[1] / std::max(tot[5], 1.0), 100 * tot[2] / all, tot[6] / prof_waves,
                      tot[2] / std::max(tot[6], 1.0), 100 * tot[3] / all, tot[7] / prof_waves, tot[3] / std::max(tot[7], 1.0), 100 * tot[4] / all,
                      tot[8] / prof_waves, tot[4] / std::max(tot[8], 1.0));
+        std::fprintf(stderr, "[lrsc] sm blocks, M ticks per wave (max lane): results %.0f, ext_eval %.0f, att_done/post %.0f, prune+commit %.0f, step_entry %.0f, "
+                             "walk_end/next %.0f, prep %.0f, begin %.0f, att_entry/leaf/final %.0f\n", blk[0] / prof_waves / 1e6, blk[1] / prof_waves / 1e6,
+                     blk[2] / prof_waves / 1e6, blk[3] / prof_waves / 1e6, blk[4] / prof_waves / 1e6, blk[5] / prof_waves / 1e6, blk[6] / prof_waves / 1e6,
+                     blk[7] / prof_waves / 1e6, blk[8] / prof_waves / 1e6);
+        std::fprintf(stderr, "[lrsc] ext_eval split: parent load %.0f, acceptance ladder %.0f, children %.0f\n", blk[9] / prof_waves / 1e6, blk[10] / prof_waves / 1e6, blk[11] / prof_waves / 1e6);
         a.prof = nullptr;
     }
     if(a.trace) {

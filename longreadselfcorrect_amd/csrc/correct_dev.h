@@ -68,6 +68,7 @@ struct CorrectArgs {
     uint32_t queue_waves;            // wavefronts to launch when the queue is used
     uint32_t profile;                // per-phase tick counters in ReadOut::cyc (LRSC_CORRECT_PROFILE)
     uint32_t setup_quorum_pct;       // lanes of a wavefront (in %) that must be between walks before they set the next ones up
+    uint32_t slow_gate_sweeps;       // ... sweeps a lane with a wide frontier waits at most for company before its general commit runs
     uint32_t step_gate_pct;          // state-machine kernel: lanes inside a walk (in %) that must be at the step gate before it opens
     uint32_t max_steps;              // ... or extension steps: no new walk is started past this budget
     uint32_t max_walks;              // walks a read may run per launch before it yields (0 = no limit); keeps DP rounds even
@@ -80,6 +81,7 @@ struct CorrectArgs {
     const double* freqs_of_kmer_size;
     DevCounters* ctr;
     // debugging aid (LRSC_SM_TRACE): the state-machine kernel records (pc, request, answer) of read `trace_read` per sweep
+    uint32_t dbg_flags;              // LRSC_SM_DBG: timing ablations (work done twice; results unchanged)
     unsigned long long* prof;        // LRSC_SM_PROFILE: 16 tick / count totals per wavefront (state-machine kernel)
     uint32_t* trace;
     uint32_t trace_cap, trace_read;
@@ -88,7 +90,7 @@ struct CorrectArgs {
 hipError_t launch_correct_plan(const CorrectArgs& a, hipStream_t stream);
 hipError_t launch_correct_reads(const FmIndexDev& fm, const CorrectArgs& a, hipStream_t stream);
 // the wavefront-convergent state-machine form (correct_sm.hip): d_fm / d_args are device copies of fm / a
-hipError_t launch_correct_sm(const FmIndexDev* d_fm, const CorrectArgs* d_args, const CorrectArgs& a, bool wide, hipStream_t stream);
+hipError_t launch_correct_sm(const FmIndexDev* d_fm, const CorrectArgs* d_args, const CorrectArgs& a, bool wide, hipStream_t stream, const FmIndexDev& fm);
 // out_codes -> ASCII, packed at dst + dst_off[r]
 hipError_t launch_correct_gather(const CorrectArgs& a, const uint64_t* dst_off, char* dst, hipStream_t stream);
 

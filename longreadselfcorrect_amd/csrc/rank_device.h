@@ -392,6 +392,46 @@ __host__ __device__ __forceinline__ void update_interval_all(const StrandC<typen
     n_blk += (bl == bu) ? 1u : 2u;
 }
 
+// two updateIntervals (one per strand, possibly different codes) with all eight piece loads of each side issued before
+// anything waits: one memory round trip instead of two
+template <bool WIDE>
+__host__ __device__ __forceinline__ void update_pair_b(const StrandC<typename Lay<WIDE>::pos_t>& sa, uint32_t ca, IvT<typename Lay<WIDE>::pos_t> a,
+                                                       const StrandC<typename Lay<WIDE>::pos_t>& sb, uint32_t cb, IvT<typename Lay<WIDE>::pos_t> b,
+                                                       const uint32_t* __restrict__ mtab, IvT<typename Lay<WIDE>::pos_t>& oa,
+                                                       IvT<typename Lay<WIDE>::pos_t>& ob, uint32_t& n_blk_a, uint32_t& n_blk_b)
+{
+    using L = Lay<WIDE>;
+    using P = typename L::pos_t;
+    const P pla = a.lo, pua = a.hi + 1, plb = b.lo, pub = b.hi + 1;
+    const P bla = pla / L::kSyms, bua = pua / L::kSyms, blb = plb / L::kSyms, bub = pub / L::kSyms;
+    const uint32_t ola = (uint32_t)(pla - bla * L::kSyms), oua = (uint32_t)(pua - bua * L::kSyms);
+    const uint32_t olb = (uint32_t)(plb - blb * L::kSyms), oub = (uint32_t)(pub - bub * L::kSyms);
+    typename L::Regs raa, rba, rab, rbb;
+    L::load(sa.blocks, bla, raa);
+    L::load(sa.blocks, bua, rba);
+    L::load(sb.blocks, blb, rab);
+    L::load(sb.blocks, bub, rbb);
+    const uint64_t base_aa = block_base<WIDE>(sa.blocks, bla, ca), base_ba = block_base<WIDE>(sa.blocks, bua, ca);
+    const uint64_t base_ab = block_base<WIDE>(sb.blocks, blb, cb), base_bb = block_base<WIDE>(sb.blocks, bub, cb);
+    uint64_t caa = base_aa + block_popc<WIDE>(raa, ca, mtab + ola * L::kRow);
+    uint64_t cba = base_ba + block_popc<WIDE>(rba, ca, mtab + oua * L::kRow);
+    uint64_t cab = base_ab + block_popc<WIDE>(rab, cb, mtab + olb * L::kRow);
+    uint64_t cbb = base_bb + block_popc<WIDE>(rbb, cb, mtab + oub * L::kRow);
+    if(ca == 0) {
+        if(ola != 0 && L::flagged(raa)) caa -= dollars_in_c(sa, (uint64_t)bla * L::kSyms, (uint64_t)bla * L::kSyms + ola);
+        if(oua != 0 && L::flagged(rba)) cba -= dollars_in_c(sa, (uint64_t)bua * L::kSyms, (uint64_t)bua * L::kSyms + oua);
+    }
+    if(cb == 0) {
+        if(olb != 0 && L::flagged(rab)) cab -= dollars_in_c(sb, (uint64_t)blb * L::kSyms, (uint64_t)blb * L::kSyms + olb);
+        if(oub != 0 && L::flagged(rbb)) cbb -= dollars_in_c(sb, (uint64_t)bub * L::kSyms, (uint64_t)bub * L::kSyms + oub);
+    }
+    const P pa = pred_of(sa, ca), pb = pred_of(sb, cb);
+    oa.lo = pa + (P)caa; oa.hi = pa + (P)cba - 1;
+    ob.lo = pb + (P)cab; ob.hi = pb + (P)cbb - 1;
+    n_blk_a = (bla == bua) ? 1u : 2u;
+    n_blk_b = (blb == bub) ? 1u : 2u;
+}
+
 // BWTAlgorithms::initInterval (BWTAlgorithms.h:136-140): Occ(b, N-1) is the symbol total.
 template <class P>
 __host__ __device__ __forceinline__ IvT<P> init_interval(const StrandC<P>& s, uint32_t code)

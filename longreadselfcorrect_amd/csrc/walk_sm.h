@@ -28,6 +28,9 @@
 namespace lrsc {
 
 #define LRSC_SM __host__ __device__ inline
+// (LRSC_SM_NI marks the block-level pieces of the sweep; they are inlined like the rest so that the address space of the lane's
+//  state object -- LDS in the kernel -- is known at every access.)
+#define LRSC_SM_NI __host__ __device__ inline
 
 
 // Byte-string helpers for the stitching code.  A plain `for(t) d[t] = s[t]` over uint8_t pointers must assume d aliases
@@ -85,6 +88,24 @@ LRSC_SM void unpack_path_rc(uint8_t* __restrict__ d, const uint32_t* __restrict_
     }
 }
 
+// Where the wave-uniform context lives.  In the kernel translation unit (correct_sm.hip defines LRSC_SM_KERNEL_TU and the
+// file-scope __shared__ objects before including this header) the launch arguments, the index description and the strand
+// constants are per-wavefront LDS copies with a statically known address space; everywhere else (the CPU harness) they are
+// reached through the pointers kept in the state object.
+#if defined(__HIP_DEVICE_COMPILE__) && defined(LRSC_SM_KERNEL_TU)
+#define LRSC_A (g_sm_a)
+#define LRSC_FM (g_sm_fm)
+#define LRSC_SF (sm_strand_lds<P>(0))
+#define LRSC_SR (sm_strand_lds<P>(1))
+template <class T> __device__ __forceinline__ T* sm_global(T* p) { return p; }   // (address-space hints did not survive; accesses stay flat)
+#else
+#define LRSC_A (*A)
+#define LRSC_FM (*fm)
+#define LRSC_SF (*sFp)
+#define LRSC_SR (*sRp)
+template <class T> __host__ __device__ inline T* sm_global(T* p) { return p; }
+#endif
+
 enum : uint32_t { kReqNone = 0, kReqRank = 1, kReqTab = 2, kReqExt = 3 };
 enum : uint32_t { kReqDoA = 1u, kReqDoB = 2u, kReqSwap = 4u };
 
@@ -116,6 +137,7 @@ enum : uint32_t {
     PC_POST,
     PC_AFTER_SF_B,
     PC_PRUNE,
+    PC_PRUNE_SLOW,        // a frontier with several leaves / children: the general commit, run behind its own (rarer) gate
     PC_STEP_ENTRY,
     PC_WALK_END,
     PC_NEXT,              // between walks: next target / yield / done
@@ -171,14 +193,15 @@ __host__ __device__ __forceinline__ void sm_answer(const FmIndexDev& fm, const S
         SA.n_dollars = swap ? sR.n_dollars : sF.n_dollars; SB.n_dollars = swap ? sF.n_dollars : sR.n_dollars;
         SA.c1 = swap ? sR.c1 : sF.c1; SA.c2 = swap ? sR.c2 : sF.c2; SA.c3 = swap ? sR.c3 : sF.c3; SA.c4 = swap ? sR.c4 : sF.c4; SA.n = swap ? sR.n : sF.n;
         SB.c1 = swap ? sF.c1 : sR.c1; SB.c2 = swap ? sF.c2 : sR.c2; SB.c3 = swap ? sF.c3 : sR.c3; SB.c4 = swap ? sF.c4 : sR.c4; SB.n = swap ? sF.n : sR.n;
-        if(rq.flags & kReqDoA) {
-            const IvT<P> o = update_interval_b<WIDE>(SA, rq.ca, IvT<P>{rq.a_lo, rq.a_hi}, mtab, n_blk);
-            res.a_lo = o.lo; res.a_hi = o.hi; n_rank += 2;
-        }
-        if(rq.flags & kReqDoB) {
-            const IvT<P> o = update_interval_b<WIDE>(SB, rq.cb, IvT<P>{rq.b_lo, rq.b_hi}, mtab, n_blk);
-            res.b_lo = o.lo; res.b_hi = o.hi; n_rank += 2;
-        }
+        // a side that is not asked for searches the empty interval [0, -1] of block 0 and its answer is dropped: no branch,
+        // all loads of both sides in flight together
+        const bool doa = (rq.flags & kReqDoA) != 0, dob = (rq.flags & kReqDoB) != 0;
+        IvT<P> oa, ob;
+        uint32_t nba = 0, nbb = 0;
+        update_pair_b<WIDE>(SA, rq.ca & 3u, IvT<P>{doa ? rq.a_lo : (P)0, doa ? rq.a_hi : (P)0}, SB, rq.cb & 3u,
+                            IvT<P>{dob ? rq.b_lo : (P)0, dob ? rq.b_hi : (P)0}, mtab, oa, ob, nba, nbb);
+        if(doa) { res.a_lo = oa.lo; res.a_hi = oa.hi; n_rank += 2; n_blk += nba; }
+        if(dob) { res.b_lo = ob.lo; res.b_hi = ob.hi; n_rank += 2; n_blk += nbb; }
     } else if(rq.kind == kReqExt) {
         // element (x * 4 + f) of the lane's ex slots: f = 0,1 the rBWT pair of base x, f = 2,3 the BWT pair of base x
         IvT<P> fo[4], ro[4];
@@ -205,11 +228,11 @@ struct ReadSM {
 
     // ---- the read ----
     uint32_t r;
-    uint64_t rs;                      // first base of the read in A->codes
+    uint64_t rs;                      // first base of the read in LRSC_A.codes
     uint32_t n_seeds;
     uint8_t* ws;                      // the read's workspace
     uint32_t lq_max, pathw;           // what its variable-size regions are laid out for (ws_layout.h)
-    // chain state (pieceVec.back()'s SeedFeature fields + iterTarget); the integer counters live in A->out[r].c[]
+    // chain state (pieceVec.back()'s SeedFeature fields + iterTarget); the integer counters live in LRSC_A.out[r].c[]
     int32_t S_seedLen, S_end, S_endBest, S_maxFixed;
     bool S_isRepeat;
     uint32_t it;
@@ -242,51 +265,55 @@ struct ReadSM {
     // ATT / EXT
     uint32_t att_no, att_i;
     double att_minErr;
-    P* ex;                        // 16 values (4 extension pairs), element e of this lane at ex[e * ex_stride]
-    uint32_t ex_stride;
     // accounting
     uint32_t n_rank, n_blk, n_tab;
+    uint64_t* tkp;                // profiling: fine-grained tick accumulators (nullptr normally)
+    uint32_t lds_pad[3];          // the kernel keeps one ReadSM per lane in LDS: an odd dword count keeps same-member accesses conflict-free
 
     // ---- workspace views (ws_layout.h: fixed-size regions at constant offsets, the rest from lq_max / pathw) ----
     static constexpr uint32_t kLB = (uint32_t)sizeof(Leaf<P>);
-    LRSC_SM WsVar var() const { return ws_var_offsets(kLB, (uint32_t)sizeof(P), lq_max, A->seed_size, pathw); }
-    LRSC_SM uint32_t n9cap() const { return (lq_max > 16u ? lq_max : 16u) - A->seed_size + 1u; }
+    LRSC_SM uint8_t* wsg() const { return sm_global(ws); }
+    LRSC_SM WsVar var() const { return ws_var_offsets(kLB, (uint32_t)sizeof(P), lq_max, LRSC_A.seed_size, pathw); }
+    LRSC_SM uint32_t n9cap() const { return (lq_max > 16u ? lq_max : 16u) - LRSC_A.seed_size + 1u; }
     LRSC_SM uint32_t lqcap() const { return lq_max > 16u ? lq_max : 16u; }
-    LRSC_SM SortItem* it9f() const { return reinterpret_cast<SortItem*>(ws + ws_var_base(kLB)); }
-    LRSC_SM SortItem* it9r() const { return reinterpret_cast<SortItem*>(ws + ws_var_base(kLB)) + n9cap(); }
-    LRSC_SM P* term() const { return reinterpret_cast<P*>(ws + ws_var_base(kLB) + n9cap() * 32u); }
+    LRSC_SM SortItem* it9f() const { return reinterpret_cast<SortItem*>(wsg() + ws_var_base(kLB)); }
+    LRSC_SM SortItem* it9r() const { return reinterpret_cast<SortItem*>(wsg() + ws_var_base(kLB)) + n9cap(); }
+    LRSC_SM P* term() const { return reinterpret_cast<P*>(wsg() + ws_var_base(kLB) + n9cap() * 32u); }
     LRSC_SM uint32_t o_paths() const { return ws_al16(ws_var_base(kLB) + n9cap() * 32u + lqcap() * 4u * (uint32_t)sizeof(P)); }
-    LRSC_SM uint32_t* paths() const { return reinterpret_cast<uint32_t*>(ws + o_paths()); }
+    LRSC_SM uint32_t* paths() const { return reinterpret_cast<uint32_t*>(wsg() + o_paths()); }
     LRSC_SM uint32_t* rpaths() const { return paths() + 32u * pathw; }
     LRSC_SM uint32_t* best() const { return paths() + (32u + kMaxResults) * pathw; }
     LRSC_SM uint32_t o_next9f() const { return o_paths() + (32u + kMaxResults + 1u) * pathw * 4u; }
-    LRSC_SM uint16_t* next9f() const { return reinterpret_cast<uint16_t*>(ws + o_next9f()); }
+    LRSC_SM uint16_t* next9f() const { return reinterpret_cast<uint16_t*>(wsg() + o_next9f()); }
     LRSC_SM uint16_t* next9r() const { return next9f() + n9cap(); }
-    LRSC_SM uint16_t* next5() const { return next9f() + 2u * n9cap(); }
-    LRSC_SM uint8_t* flags5() const { return ws + o_next9f() + 4u * n9cap() + 2u * (lqcap() - 4u); }
+    // per query offset: 5-mer code | (fwd interval valid) << 10 | (rvc interval valid) << 11   (PREP writes it)
+    LRSC_SM uint16_t* c5() const { return next9f() + 2u * n9cap(); }
+    LRSC_SM uint8_t* flags5() const { return wsg() + o_next9f() + 4u * n9cap() + 2u * (lqcap() - 4u); }
     LRSC_SM uint8_t* q() const { return flags5() + (lqcap() - 4u); }
     LRSC_SM uint8_t* dpq() const { return q() + lqcap(); }
-    LRSC_SM uint16_t* head9f() const { return reinterpret_cast<uint16_t*>(ws + ws_fixed_head9(kLB)); }
+    LRSC_SM uint16_t* head9f() const { return reinterpret_cast<uint16_t*>(wsg() + ws_fixed_head9(kLB)); }
     LRSC_SM uint16_t* head9r() const { return head9f() + 256; }
-    LRSC_SM uint16_t* head5() const { return reinterpret_cast<uint16_t*>(ws + ws_fixed_head5(kLB)); }
-    LRSC_SM LeafT* cur() const { return reinterpret_cast<LeafT*>(ws); }
-    LRSC_SM LeafT* nxt() const { return reinterpret_cast<LeafT*>(ws) + 32; }
+    LRSC_SM uint16_t* head5() const { return reinterpret_cast<uint16_t*>(wsg() + ws_fixed_head5(kLB)); }
+    LRSC_SM LeafT* cur() const { return reinterpret_cast<LeafT*>(wsg()); }
+    LRSC_SM LeafT* nxt() const { return reinterpret_cast<LeafT*>(wsg()) + 32; }
     LRSC_SM LeafT* leaves(uint32_t list) const { return list ? nxt() : cur(); }
-    LRSC_SM double* rings() const { return reinterpret_cast<double*>(ws + ws_fixed_rings(kLB)); }
-    LRSC_SM WalkResultRec* results() const { return reinterpret_cast<WalkResultRec*>(ws + ws_fixed_results(kLB)); }
+    LRSC_SM double* rings() const { return reinterpret_cast<double*>(wsg() + ws_fixed_rings(kLB)); }
+    LRSC_SM WalkResultRec* results() const { return reinterpret_cast<WalkResultRec*>(wsg() + ws_fixed_results(kLB)); }
     // read-level views, recomputed where needed (used between walks only)
-    LRSC_SM const uint8_t* read() const { return A->codes + rs; }
-    LRSC_SM const int32_t* seeds() const { return A->seeds + seed_slab(rs, r, A->min_k) * kSeedInts; }
-    LRSC_SM uint8_t* out() const { return A->out_codes + A->work[r].out_off; }
-    LRSC_SM uint32_t* piece_start() const { return A->piece_start + A->work[r].piece_off; }
-    LRSC_SM uint32_t out_cap() const { return A->work[r].out_cap; }
-    LRSC_SM int64_t& ctr(int j) const { return A->out[r].c[j]; }
-    LRSC_SM const StrandC<P>& sF() const { return *sFp; }
-    LRSC_SM const StrandC<P>& sR() const { return *sRp; }
-    LRSC_SM P& exv(uint32_t b, uint32_t f) const { return ex[(b * 4u + f) * ex_stride]; }
+    LRSC_SM const uint8_t* read() const { return sm_global(LRSC_A.codes) + rs; }
+    LRSC_SM const int32_t* seeds() const { return sm_global(LRSC_A.seeds) + seed_slab(rs, r, LRSC_A.min_k) * kSeedInts; }
+    LRSC_SM uint8_t* out() const { return sm_global(LRSC_A.out_codes) + sm_global(LRSC_A.work)[r].out_off; }
+    LRSC_SM uint32_t* piece_start() const { return sm_global(LRSC_A.piece_start) + sm_global(LRSC_A.work)[r].piece_off; }
+    LRSC_SM uint32_t out_cap() const { return sm_global(LRSC_A.work)[r].out_cap; }
+    LRSC_SM int64_t& ctr(int j) const { return sm_global(LRSC_A.out)[r].c[j]; }
+    LRSC_SM const StrandC<P>& sF() const { return LRSC_SF; }
+    LRSC_SM const StrandC<P>& sR() const { return LRSC_SR; }
+    // the lane's extension slots are passed down from the kernel (an LDS pointer the compiler can see), not read back from the
+    // state object: a pointer loaded from memory is generic, and generic (flat) accesses to LDS are slow and serialising
+    static LRSC_SM P& exv(P* ex, uint32_t ex_stride, uint32_t b, uint32_t f) { return ex[(b * 4u + f) * ex_stride]; }
 
-    LRSC_SM uint32_t seedSize() const { return A->seed_size; }
-    LRSC_SM uint32_t minOverlap() const { return A->min_overlap; }
+    LRSC_SM uint32_t seedSize() const { return LRSC_A.seed_size; }
+    LRSC_SM uint32_t minOverlap() const { return LRSC_A.min_overlap; }
 
     // ---- request helpers ----------------------------------------------------------------------------------
     LRSC_SM void req_rank(P alo, P ahi, uint32_t ca, bool doa, P blo, P bhi, uint32_t cb, bool dob, bool swap)
@@ -301,16 +328,16 @@ struct ReadSM {
     LRSC_SM int best_table(uint32_t max_k) const
     {
         int b = -1;
-        if(fm->ktab[0].k != 0 && fm->ktab[0].k <= max_k) b = 0;
-        if(fm->ktab[1].k != 0 && fm->ktab[1].k <= max_k) b = 1;
-        if(fm->ktab[2].k != 0 && fm->ktab[2].k <= max_k) b = 2;
-        if(fm->ktab[3].k != 0 && fm->ktab[3].k <= max_k) b = 3;
-        if(fm->ktab[4].k != 0 && fm->ktab[4].k <= max_k) b = 4;
+        if(LRSC_FM.ktab[0].k != 0 && LRSC_FM.ktab[0].k <= max_k) b = 0;
+        if(LRSC_FM.ktab[1].k != 0 && LRSC_FM.ktab[1].k <= max_k) b = 1;
+        if(LRSC_FM.ktab[2].k != 0 && LRSC_FM.ktab[2].k <= max_k) b = 2;
+        if(LRSC_FM.ktab[3].k != 0 && LRSC_FM.ktab[3].k <= max_k) b = 3;
+        if(LRSC_FM.ktab[4].k != 0 && LRSC_FM.ktab[4].k <= max_k) b = 4;
         return b;
     }
     LRSC_SM uint32_t table_k(int t) const
     {
-        return t == 0 ? fm->ktab[0].k : t == 1 ? fm->ktab[1].k : t == 2 ? fm->ktab[2].k : t == 3 ? fm->ktab[3].k : fm->ktab[4].k;
+        return t == 0 ? LRSC_FM.ktab[0].k : t == 1 ? LRSC_FM.ktab[1].k : t == 2 ? LRSC_FM.ktab[2].k : t == 3 ? LRSC_FM.ktab[3].k : LRSC_FM.ktab[4].k;
     }
     // characters [t0, t0 + k) (0 = oldest) of the suffix of length l of a packed path, first character in the high bits
     static LRSC_SM uint32_t suf_code(uint64_t lo, uint64_t hi, uint32_t l, uint32_t t0, uint32_t k)
@@ -339,7 +366,7 @@ struct ReadSM {
         pc = PC_FS;
         fs_advance();
     }
-    LRSC_SM void fs_advance()
+    LRSC_SM_NI void fs_advance()
     {
         while(true) {
             if(m_start) {
@@ -412,14 +439,14 @@ struct ReadSM {
         if(lf.tmpFreq > sf_max) sf_max = lf.tmpFreq;
     }
     LRSC_SM void sf_finish(uint64_t result) { sf_result = result; pc = m_ret; }
-    LRSC_SM void sf_advance()
+    LRSC_SM_NI void sf_advance()
     {
         const uint32_t U = sf_UB, Lw = sf_LB;
         while(true) {
             if(sf_phase == 1) {
                 if(m_start) {
                     if(m_j >= m_n) {
-                        if(sf_max - (int)A->freqs_of_kmer_size[sf_LB] < 5) { sf_finish(sf_LB); return; }
+                        if(sf_max - (int)LRSC_A.freqs_of_kmer_size[sf_LB] < 5) { sf_finish(sf_LB); return; }
                         if(sf_UB == sf_LB) { sf_finish(sf_UB); return; }
                         sf_phase = 2; sf_i = 1; m_j = 0; sf_max = 0;
                         continue;
@@ -458,7 +485,7 @@ struct ReadSM {
             } else {
                 // phase 2: extend every leaf's pair by one more (older) character, no validity check (.cpp:317-318)
                 if(m_j >= m_n) {
-                    if(sf_max - (int)A->freqs_of_kmer_size[sf_LB + sf_i] < 5) { sf_finish(sf_LB + sf_i); return; }
+                    if(sf_max - (int)LRSC_A.freqs_of_kmer_size[sf_LB + sf_i] < 5) { sf_finish(sf_LB + sf_i); return; }
                     ++sf_i;
                     if(sf_i > sf_UB - sf_LB) { sf_finish(sf_UB); return; }
                     m_j = 0; sf_max = 0;
@@ -499,7 +526,7 @@ struct ReadSM {
     LRSC_SM bool isInsufficientFreqs(const LeafT* lv, uint32_t n) const             // .cpp:334-352
     {
         uint64_t highfreqscount = 0;
-        const uint64_t cov = A->pb_coverage;
+        const uint64_t cov = LRSC_A.pb_coverage;
         for(uint32_t i = 0; i < n; ++i) {
             const int highfreqThreshold = cov > 60 ? (int)((uint64_t)(cov / 60) * 3) : 3;
             if(lv[i].kmerFrequency > highfreqThreshold) highfreqscount++;
@@ -510,42 +537,70 @@ struct ReadSM {
         return false;
     }
 
-    LRSC_SM bool ismatchedbykmer(uint32_t code5, bool fvalid, bool rvalid) const      // .cpp:787-821
+    // ismatchedbykmer (.cpp:787-821) for the four extension bases at once: bit x of the result = some offset j of the query
+    // inside the indel window carries the 5-mer (last four path characters + x) with a valid interval on a strand whose
+    // extended interval is valid too.  The reference asks two interval trees; here the window of per-offset codes is read
+    // in independent loads (no chain to follow).
+    LRSC_SM_NI uint32_t matched_by_5mer(uint32_t suf8, uint32_t fvalid4, uint32_t rvalid4) const
     {
-        const uint64_t startSeedIdx = (uint64_t)(((int)currentLength - (int)maxIndelSize) > 0 ? ((int)currentLength - (int)maxIndelSize) : 0);
-        const uint64_t largeSeedIdx = currentLength + maxIndelSize;
-        const uint16_t* n5 = next5();
-        const uint8_t* f5 = flags5();
-        for(uint32_t j = head5()[code5]; j != 0xFFFFu; j = n5[j]) {
-            if(j >= startSeedIdx && j <= largeSeedIdx) {
-                const uint32_t fl = f5[j];
-                if((fvalid && (fl & 1)) || (rvalid && (fl & 2))) return true;
+        const uint32_t startSeedIdx = (uint32_t)(((int)currentLength - (int)maxIndelSize) > 0 ? ((int)currentLength - (int)maxIndelSize) : 0);
+        uint32_t largeSeedIdx = currentLength + maxIndelSize;
+        const uint32_t n5 = Lq >= 5 ? Lq - 5 + 1 : 0;
+        if(n5 == 0 || startSeedIdx >= n5) return 0;
+        if(largeSeedIdx > n5 - 1) largeSeedIdx = n5 - 1;
+        const uint16_t* cc = c5();
+        const uint32_t pre = (suf8 & 0xFFu) << 2;                 // the 5-mer code without its last character
+        uint32_t mask = 0;
+        // whole 16-byte chunks (8 entries) that cover the window: one wide load each (the array starts 16-byte aligned + even)
+        const uintptr_t base = reinterpret_cast<uintptr_t>(cc);
+        const uintptr_t a0 = (base + 2u * startSeedIdx) & ~(uintptr_t)15, a1 = base + 2u * largeSeedIdx;
+        for(uintptr_t a = a0; a <= a1; a += 64) {
+            uint4 v[4];
+#pragma unroll
+            for(uint32_t u = 0; u < 4; ++u) v[u] = a + 16u * u <= a1 ? *reinterpret_cast<const uint4*>(a + 16u * u) : uint4{0, 0, 0, 0};
+#pragma unroll
+            for(uint32_t u = 0; u < 4; ++u) {
+                const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                for(uint32_t h = 0; h < 8; ++h) {
+                    const uintptr_t ea = a + 16u * u + 2u * h;
+                    const uint32_t e = (w[h >> 1] >> (16u * (h & 1u))) & 0xFFFFu;
+                    if(ea < base + 2u * startSeedIdx || ea > a1) continue;
+                    if(((e ^ pre) & 0x3FCu) != 0 || (e & 0xC00u) == 0) continue;
+                    const uint32_t x = e & 3u;
+                    const bool ok = (((fvalid4 >> x) & 1u) && (e & 0x400u)) || (((rvalid4 >> x) & 1u) && (e & 0x800u));
+                    if(ok) mask |= 1u << x;
+                }
             }
         }
-        return false;
+        return mask;
     }
 
     // the acceptance ladder of getFMIndexExtensions (.cpp:700-784) over the four extension pairs in ex_*
-    LRSC_SM uint32_t ext_mask(const LeafT& lf, int* freq) const
+    LRSC_SM_NI uint32_t ext_mask(const LeafT& lf, int* freq, P* ex, uint32_t ex_stride) const
     {
         const uint64_t IntervalSizeCutoff = min_SA_threshold;
         uint64_t totalcount = 0;
         int maxfreqsofleave = 0;
         for(uint32_t b = 0; b < 4; ++b) {
-            freq[b] = (int)(isize(exv(b, 0), exv(b, 1)) + isize(exv(b, 2), exv(b, 3)));
+            freq[b] = (int)(isize(exv(ex, ex_stride, b, 0), exv(ex, ex_stride, b, 1)) + isize(exv(ex, ex_stride, b, 2), exv(ex, ex_stride, b, 3)));
             totalcount += (uint64_t)(int64_t)freq[b];
             if(freq[b] > maxfreqsofleave) maxfreqsofleave = freq[b];
         }
         uint32_t mask = 0;
         const bool isHomopolymer = lf.tailLetterCount >= 3;
+        uint32_t fvalid4 = 0, rvalid4 = 0;
+        for(uint32_t b = 0; b < 4; ++b) {
+            if(exv(ex, ex_stride, b, 0) <= exv(ex, ex_stride, b, 1)) fvalid4 |= 1u << b;
+            if(exv(ex, ex_stride, b, 2) <= exv(ex, ex_stride, b, 3)) rvalid4 |= 1u << b;
+        }
+        uint32_t matched4 = matched_by_5mer((uint32_t)lf.suf_lo, fvalid4, rvalid4);
         for(uint32_t b = 0; b < 4; ++b) {
             const uint64_t kmerFreq = (uint64_t)(int64_t)freq[b];
             const double kmerRatioNotPass = 2;
             double kmerRatioCutoff = 0;
             const double kmerRatio = (double)kmerFreq / (double)maxfreqsofleave;
-            const bool efv = exv(b, 0) <= exv(b, 1), erv = exv(b, 2) <= exv(b, 3);
-            const uint32_t code5 = (uint32_t)(((lf.suf_lo << 2) | b) & 0x3FFu);
-            const bool isMatchedBy5mer = ismatchedbykmer(code5, efv, erv);
+            const bool isMatchedBy5mer = ((matched4 >> b) & 1u) != 0;
             const bool isFreqPass = kmerFreq >= IntervalSizeCutoff;
             const bool isLowCoverage = totalcount >= IntervalSizeCutoff + 2;
             const bool isRepeat = maxfreqsofleave > 100;
@@ -580,7 +635,7 @@ struct ReadSM {
         return c;
     }
 
-    LRSC_SM bool isSupportedByNewSeed(LeafT& nd, uint64_t smallSeedIdx, uint64_t largeSeedIdx)     // .cpp:566-635
+    LRSC_SM_NI bool isSupportedByNewSeed(LeafT& nd, uint64_t smallSeedIdx, uint64_t largeSeedIdx)     // .cpp:566-635
     {
         const uint32_t seedSz = seedSize();
         const uint64_t seedIdxOffset = nd.lastOverlapLen < currentLength - seedSz ? (uint64_t)seedSz : currentLength - nd.lastOverlapLen;
@@ -595,8 +650,8 @@ struct ReadSM {
         const uint16_t* nf = next9f(); const uint16_t* nr = next9r();
         uint32_t jf = fv ? head9f()[hb] : 0xFFFFu;
         uint32_t jr = rv ? head9r()[hb] : 0xFFFFu;
-        while(jf != 0xFFFFu && kmer_code(i9f[jf].val) != code9) jf = nf[jf];
-        while(jr != 0xFFFFu && kmer_code(i9r[jr].val) != code9) jr = nr[jr];
+        while(jf != 0xFFFFu && i9f[jf].pad != code9) jf = nf[jf];
+        while(jr != 0xFFFFu && i9r[jr].pad != code9) jr = nr[jr];
         int minIdxDiff = 10000;
         const uint64_t currSeedIdx = currentLength - seedSz;
         while(jf != 0xFFFFu || jr != 0xFFFFu) {
@@ -614,8 +669,8 @@ struct ReadSM {
                 nd.currOverlapLen = currentLength;
                 isNewSeedFound = true;
             }
-            if(jf != 0xFFFFu) { jf = nf[jf]; while(jf != 0xFFFFu && kmer_code(i9f[jf].val) != code9) jf = nf[jf]; }
-            if(jr != 0xFFFFu) { jr = nr[jr]; while(jr != 0xFFFFu && kmer_code(i9r[jr].val) != code9) jr = nr[jr]; }
+            if(jf != 0xFFFFu) { jf = nf[jf]; while(jf != 0xFFFFu && i9f[jf].pad != code9) jf = nf[jf]; }
+            if(jr != 0xFFFFu) { jr = nr[jr]; while(jr != 0xFFFFu && i9r[jr].pad != code9) jr = nr[jr]; }
         }
         if(isNewSeedFound) nd.totalSeeds++;
         return isNewSeedFound;
@@ -640,39 +695,37 @@ struct ReadSM {
         return currErrorRate;
     }
 
-    LRSC_SM void PrunedBySeedSupport()                                                          // .cpp:491-563
+    // PrunedBySeedSupport (.cpp:491-563) for one child held in registers.  A child still carries its parent's ring slot id
+    // (createChild copies it; the commit assigns the final one), so the parent's error history is found without reading the parent.
+    LRSC_SM void prune_child(LeafT& leaf)
     {
         const uint32_t seedSz = seedSize();
-        const double PacBioErrorRate = A->pacbio_error_rate;
+        const double PacBioErrorRate = LRSC_A.pacbio_error_rate;
         const uint64_t currSeedIdx = currentLength - seedSz;
         const uint64_t indelOffset = seedSz + maxIndelSize;
         const uint64_t smallSeedIdx = currSeedIdx <= indelOffset ? 0 : currSeedIdx - indelOffset;
         const uint64_t largeSeedIdx = (currSeedIdx + indelOffset) >= (Lq - seedSz) ? (Lq - seedSz) : currSeedIdx + indelOffset;
-        LeafT* nx = nxt(); const LeafT* cu = cur();
-        for(uint32_t c = 0; c < n_nxt; ++c) {
-            LeafT& leaf = nx[c];
-            bool isNewSeedFound = false;
-            if(currentLength - leaf.lastOverlapLen > seedSz || currentLength - leaf.lastOverlapLen <= 1) {
-                const uint64_t preSeedIdx = leaf.lastSeedIdx;
-                isNewSeedFound = isSupportedByNewSeed(leaf, smallSeedIdx, largeSeedIdx);
-                if(isNewSeedFound) {
-                    if(currSeedIdx + (uint64_t)(int64_t)leaf.lastSeedIdxOffset - preSeedIdx > seedSz)
-                        leaf.numRedeemSeed += (seedSz - 1) * PacBioErrorRate;
-                    leaf.lastSeedIdxOffset = (int)leaf.lastSeedIdx - (int)currSeedIdx;
-                } else {
-                    const uint64_t v = currSeedIdx + (uint64_t)(int64_t)leaf.lastSeedIdxOffset - leaf.lastSeedIdx;
-                    if(v % seedSz == 1) leaf.numOfErrors++;
-                    else if(v > (uint64_t)seedSz - 1) leaf.numRedeemSeed += 1 - PacBioErrorRate;
-                }
-            } else
-                leaf.numRedeemSeed += 1 - PacBioErrorRate;
-            const double* pring = rings() + (uint64_t)cu[leaf.parent].ring * 100;
-            const double currErrorRate = computeErrorRate(leaf, pring);
-            if(currErrorRate > 0.25) leaf.alive = 0;
-        }
+        bool isNewSeedFound = false;
+        if(currentLength - leaf.lastOverlapLen > seedSz || currentLength - leaf.lastOverlapLen <= 1) {
+            const uint64_t preSeedIdx = leaf.lastSeedIdx;
+            isNewSeedFound = isSupportedByNewSeed(leaf, smallSeedIdx, largeSeedIdx);
+            if(isNewSeedFound) {
+                if(currSeedIdx + (uint64_t)(int64_t)leaf.lastSeedIdxOffset - preSeedIdx > seedSz)
+                    leaf.numRedeemSeed += (seedSz - 1) * PacBioErrorRate;
+                leaf.lastSeedIdxOffset = (int)leaf.lastSeedIdx - (int)currSeedIdx;
+            } else {
+                const uint64_t v = currSeedIdx + (uint64_t)(int64_t)leaf.lastSeedIdxOffset - leaf.lastSeedIdx;
+                if(v % seedSz == 1) leaf.numOfErrors++;
+                else if(v > (uint64_t)seedSz - 1) leaf.numRedeemSeed += 1 - PacBioErrorRate;
+            }
+        } else
+            leaf.numRedeemSeed += 1 - PacBioErrorRate;
+        const double* pring = rings() + (uint64_t)leaf.ring * 100;
+        const double currErrorRate = computeErrorRate(leaf, pring);
+        if(currErrorRate > 0.25) leaf.alive = 0;
     }
 
-    LRSC_SM void terminated_leaf(LeafT& lf, const uint32_t* pw, uint32_t plen, int extra)         // .cpp:825-878
+    LRSC_SM_NI void terminated_leaf(LeafT& lf, const uint32_t* pw, uint32_t plen, int extra)         // .cpp:825-878
     {
         const bool fvalid = lf.flo <= lf.fhi, rvalid = lf.rlo <= lf.rhi;
         const uint64_t i0 = (uint64_t)(lf.res_second > 0 ? lf.res_second : 0);
@@ -705,7 +758,7 @@ struct ReadSM {
     }
 
     // interval "trees" (IntervalTree.cpp:4-48 -> k-mer chains in std::sort's order) + the root's bookkeeping
-    LRSC_SM void begin_walk()
+    LRSC_SM_NI void begin_walk()
     {
         const uint32_t seedSz = seedSize();
         const uint8_t* qq = q();
@@ -720,21 +773,11 @@ struct ReadSM {
             introsort(itx, (int64_t)n);
             for(uint32_t b = 0; b < 256; ++b) head[b] = 0xFFFFu;
             for(uint32_t j = n; j-- > 0;) {                       // prepend walking backwards: chains keep the post-sort order
-                const uint32_t code = kmer_code(itx[j].val);
+                const uint32_t code = itx[j].pad;                  // the idmer's 2-bit code, stored by PREP
                 const uint32_t hb = (code ^ (code >> 9)) & 255u;
                 nextp[j] = head[hb];
                 head[hb] = (uint16_t)j;
             }
-        }
-        uint16_t* h5 = head5(); uint16_t* n5p = next5(); const uint8_t* f5 = flags5();
-        for(uint32_t c = 0; c < 1024; ++c) h5[c] = 0xFFFFu;
-        const uint32_t n5 = Lq >= 5 ? Lq - 5 + 1 : 0;
-        for(uint32_t i = n5; i-- > 0;) {
-            if(f5[i] == 0) continue;
-            uint32_t code = 0;
-            for(uint32_t t = 0; t < 5; ++t) code = (code << 2) | qq[i + t];
-            n5p[i] = h5[code];
-            h5[code] = (uint16_t)i;
         }
         // root (initialRootNode, .cpp:108-124; leafInfo ctor, .h:156-171)
         slot_free = 0xFFFFFFFEu;
@@ -764,7 +807,7 @@ struct ReadSM {
     }
 
     // attempToExtend's prologue (.cpp:373-398): drop leaves whose local error rate is far from the best one
-    LRSC_SM void att_entry()
+    LRSC_SM_NI void att_entry()
     {
         const uint64_t localK = 100;
         LeafT* cu = cur();
@@ -799,46 +842,55 @@ struct ReadSM {
     }
     // all four extension pairs of leaf att_i are in ex: the acceptance ladder, at most twice (second time with the threshold
     // lowered by one, only for the best leaf of a multi-leaf frontier: .cpp:403-421), then updateLeaves (:468-488)
-    LRSC_SM void ext_eval()
+    LRSC_SM_NI void ext_eval(P* ex, uint32_t ex_stride)
     {
-        LeafT* cu = cur();
-        const LeafT& par = cu[att_i];
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LRSC_SM_T2() (tkp ? (uint64_t)__builtin_readcyclecounter() : 0ull)
+#else
+#define LRSC_SM_T2() 0ull
+#endif
+        uint64_t t_a = LRSC_SM_T2();
+        LeafT par = cur()[att_i];                                  // one struct load; everything below works on registers
+        if(tkp) { const uint64_t t_b = LRSC_SM_T2(); tkp[9] += t_b - t_a; t_a = t_b; }
         int freq[4];
         uint32_t mask = 0;
         int count = 0;
         while(count < 2) {
             if(count == 1 && !(par.localErr == att_minErr && n_cur > 1)) break;
-            mask = ext_mask(par, freq);
+            mask = ext_mask(par, freq, ex, ex_stride);
             if(mask != 0) break;
             min_SA_threshold--;
             count++;
         }
         min_SA_threshold += (uint32_t)count;
-        if(mask != 0) {
-            LeafT* nx = nxt();
-            for(uint32_t bb = 0; bb < 4; ++bb) {
-                if(!(mask & (1u << bb))) continue;
-                if(n_nxt >= kMaxChildren) { error = LRSC_WALK_ERR_CHILDREN; pc = PC_WALK_END; return; }
-                LeafT& ch = nx[n_nxt++];
-                ch = par;                                          // createChild copies the node state (SAINode.cpp:166-189)
-                ch.flo = exv(bb, 0); ch.fhi = exv(bb, 1); ch.rlo = exv(bb, 2); ch.rhi = exv(bb, 3);
-                ch.kmerFrequency = freq[bb];
-                ch.currOverlapLen++;
-                ch.queryOverlapLen++;
-                if(par.tailLetter == bb) ch.tailLetterCount = par.tailLetterCount + 1;
-                else { ch.tailLetter = bb; ch.tailLetterCount = 1; }
-                suf_push(ch, bb);
-                ch.parent = (uint16_t)att_i;
-                ch.ext = (uint8_t)bb;
-                ch.alive = 1;
-            }
+        if(tkp) { const uint64_t t_b = LRSC_SM_T2(); tkp[10] += t_b - t_a; t_a = t_b; }
+        // updateLeaves: children in base order.  The loop runs over the lane's accepted bases (one, mostly), not over the four
+        // bases: every iteration is a whole-struct store for the wavefront, whoever takes part
+        LeafT* nx = nxt();
+        for(uint32_t rest = mask; rest != 0; rest &= rest - 1u) {
+            uint32_t bb = 0;
+            while(!((rest >> bb) & 1u)) ++bb;
+            if(n_nxt >= kMaxChildren) { error = LRSC_WALK_ERR_CHILDREN; pc = PC_WALK_END; return; }
+            LeafT ch = par;                                        // createChild copies the node state (SAINode.cpp:166-189)
+            ch.flo = exv(ex, ex_stride, bb, 0); ch.fhi = exv(ex, ex_stride, bb, 1); ch.rlo = exv(ex, ex_stride, bb, 2); ch.rhi = exv(ex, ex_stride, bb, 3);
+            ch.kmerFrequency = bb == 0 ? freq[0] : bb == 1 ? freq[1] : bb == 2 ? freq[2] : freq[3];
+            ch.currOverlapLen++;
+            ch.queryOverlapLen++;
+            if(par.tailLetter == bb) ch.tailLetterCount = par.tailLetterCount + 1;
+            else { ch.tailLetter = bb; ch.tailLetterCount = 1; }
+            suf_push(ch, bb);
+            ch.parent = (uint16_t)att_i;
+            ch.ext = (uint8_t)bb;
+            ch.alive = 1;
+            nx[n_nxt++] = ch;
         }
+        if(tkp) { const uint64_t t_b = LRSC_SM_T2(); tkp[11] += t_b - t_a; t_a = t_b; }
         ++att_i;
         pc = att_i >= n_cur ? PC_ATT_DONE : PC_ATT_LEAF;          // ATT_DONE's block comes later in this same sweep
     }
 
     // extendLeaves' control flow after an attempToExtend (.cpp:239-278)
-    LRSC_SM void att_done()
+    LRSC_SM_NI void att_done()
     {
         if(n_nxt == 0) {
             if(att_no == 1) {                                   // level 1: reduce the k-mer size
@@ -856,7 +908,7 @@ struct ReadSM {
         if(att_no == 3) min_SA_threshold++;
         pc = PC_POST;
     }
-    LRSC_SM void post()
+    LRSC_SM_NI void post()
     {
         if(n_nxt != 0) {
             currentLength++;
@@ -871,14 +923,47 @@ struct ReadSM {
     }
 
     // PrunedBySeedSupport + the rest of one extendOverlap iteration (.cpp:155-211)
-    LRSC_SM void prune_and_commit()
+    // the common shape (one leaf, one accepted base) is committed at the step gate; anything wider waits for the slow gate: the
+    // general commit is several times the instructions, and a wavefront pays a block's instructions however few lanes run it
+    LRSC_SM bool prune_is_simple() const { return n_nxt == 1 && n_cur == 1 && LRSC_A.max_leaves >= 1; }
+    LRSC_SM_NI void prune_and_commit()
     {
-        PrunedBySeedSupport();
         LeafT* nx = nxt(); LeafT* cu = cur();
+        if(prune_is_simple()) {
+            // the common shape (one leaf, one accepted base): the child stays in registers from the pruning to the commit
+            LeafT ch = nx[0];
+            prune_child(ch);
+            ++steps;
+            if(!ch.alive) {
+                free_leaf_slots(cu[0]);
+                n_cur = 0;
+                pc = PC_STEP_ENTRY;
+                return;
+            }
+            // it takes over the parent's ring and path in place (SAINode::extend)
+            rings()[(uint64_t)ch.ring * 100 + (ch.hist_size - 1) % 100] = ch.globalErr;     // GlobalErrorRateRecord.push_back
+            uint32_t* pw = paths() + (uint64_t)ch.path * pathw;
+            path_set(pw, ch.path_len, ch.ext);
+            ch.path_len++;
+            if(currentLength >= minLength) {
+                terminated_leaf(ch, pw, ch.path_len, -1);
+                if(error) { pc = PC_WALK_END; return; }
+            }
+            cu[0] = ch;
+            n_cur = 1;
+            pc = PC_STEP_ENTRY;
+            return;
+        }
+        for(uint32_t c = 0; c < n_nxt; ++c) {
+            LeafT leaf = nx[c];
+            prune_child(leaf);
+            nx[c] = leaf;
+        }
+        const uint32_t pathw = this->pathw;
         uint32_t survivors = 0;
         for(uint32_t c = 0; c < n_nxt; ++c) survivors += nx[c].alive;
         ++steps;
-        if(survivors > A->max_leaves) {
+        if(survivors > LRSC_A.max_leaves) {
             if(currentLength >= minLength)
                 for(uint32_t c = 0; c < n_nxt; ++c) {
                     if(!nx[c].alive) continue;
@@ -930,16 +1015,16 @@ struct ReadSM {
     }
 
     // loop condition of extendOverlap + the head of extendLeaves
-    LRSC_SM void step_entry()
+    LRSC_SM_NI void step_entry()
     {
-        if(ended || error || !(n_cur != 0 && n_cur <= A->max_leaves && currentLength <= maxLength)) { pc = PC_WALK_END; return; }
+        if(ended || error || !(n_cur != 0 && n_cur <= LRSC_A.max_leaves && currentLength <= maxLength)) { pc = PC_WALK_END; return; }
         n_nxt = 0;
         att_no = 1;
         if(currentKmerSize > maxOverlap) { fs_begin(0, n_cur, maxOverlap, PC_ATT_ENTRY, true); return; }
         pc = PC_ATT_ENTRY;
     }
 
-    LRSC_SM int finish_walk(uint32_t* out_len_, uint32_t* out_words, uint32_t* out_match_i)      // findTheBestPath (.cpp:214-236)
+    LRSC_SM_NI int finish_walk(uint32_t* out_len_, uint32_t* out_words, uint32_t* out_match_i)      // findTheBestPath (.cpp:214-236)
     {
         if(error) return error;
         if(n_results > 0) {
@@ -958,7 +1043,7 @@ struct ReadSM {
         }
         if(n_cur == 0) return -1;
         else if(currentLength > maxLength) return -2;
-        else if(n_cur > A->max_leaves) return -3;
+        else if(n_cur > LRSC_A.max_leaves) return -3;
         return -4;
     }
 
@@ -966,15 +1051,21 @@ struct ReadSM {
     // PREP: the constructor's per-offset searches (.cpp:82-94,127-152): bi-intervals of the 5-mer, the idmer and,
     // inside the target seed, the minOverlap-mer starting at every offset of m_query
     // =========================================================================================================
-    LRSC_SM void prep_emit()
+    LRSC_SM_NI void prep_emit()
     {
         const uint32_t i = m_j, s = m_t;
         const bool fval = m_flo <= m_fhi, rval = m_rlo <= m_rhi;
-        if(s == 5) flags5()[i] = (uint8_t)((fval ? 1 : 0) | (rval ? 2 : 0));
+        if(s == 5) {
+            const uint8_t* qq = q();
+            uint32_t code = 0;
+            for(uint32_t t = 0; t < 5; ++t) code = (code << 2) | qq[i + t];
+            c5()[i] = (uint16_t)(code | (fval ? 0x400u : 0u) | (rval ? 0x800u : 0u));
+        }
         if(s == seedSize()) {
             SortItem* a = it9f() + i; SortItem* b = it9r() + i;
-            a->key = fval ? (uint64_t)m_flo : kNoKey; a->val = i; a->pad = 0;
-            b->key = rval ? (uint64_t)m_rlo : kNoKey; b->val = i; b->pad = 0;
+            const uint32_t code = kmer_code(i);
+            a->key = fval ? (uint64_t)m_flo : kNoKey; a->val = i; a->pad = code;
+            b->key = rval ? (uint64_t)m_rlo : kNoKey; b->val = i; b->pad = code;
         }
         if(s == minOverlap() && m_flag) {
             P* t = term() + (uint64_t)(i - (uint32_t)(k + interval)) * 4;
@@ -990,8 +1081,8 @@ struct ReadSM {
     // one entry of table t: {fwd.lo, fwd.hi, rvc.lo, rvc.hi}
     LRSC_SM void table_entry(int t, uint32_t code, P e[4]) const
     {
-        const void* tabv = t == 0 ? fm->ktab[0].entries : t == 1 ? fm->ktab[1].entries : t == 2 ? fm->ktab[2].entries
-                         : t == 3 ? fm->ktab[3].entries : fm->ktab[4].entries;
+        const void* tabv = t == 0 ? LRSC_FM.ktab[0].entries : t == 1 ? LRSC_FM.ktab[1].entries : t == 2 ? LRSC_FM.ktab[2].entries
+                         : t == 3 ? LRSC_FM.ktab[3].entries : LRSC_FM.ktab[4].entries;
         if(WIDE) {
             const uint4* tp = reinterpret_cast<const uint4*>(tabv) + (uint64_t)code * 2;
             const uint4 a = tp[0], b = tp[1];
@@ -1004,51 +1095,84 @@ struct ReadSM {
     }
     // PREP when tables of exactly the three sizes exist (the normal configuration: 5, idmer = 9, minOverlap = 13): every emit
     // of an offset is one table entry, nothing chains, so kPrepBatch offsets are answered per sweep with all look-ups in flight.
-    static constexpr uint32_t kPrepBatch = 4;
-    LRSC_SM bool prep_fast()
+    static constexpr uint32_t kPrepBatch = 16;
+    LRSC_SM_NI bool prep_fast()
     {
         const uint32_t seedk = seedSize(), mink = minOverlap();
-        if(seedk <= 5 || mink <= seedk) return false;
+        if(seedk <= 5 || mink <= seedk || mink > 16) return false;
         const int t5 = table_of(5), t9 = table_of(seedk), t13 = table_of(mink);
         if(t5 < 0 || t9 < 0 || t13 < 0) return false;
         const uint8_t* qq = q();
         const uint32_t trg0 = (uint32_t)(k + interval);
-        P e5[kPrepBatch][4], e9[kPrepBatch][4], e13[kPrepBatch][4];
-        bool d5[kPrepBatch], d9[kPrepBatch], d13[kPrepBatch];
-        for(uint32_t u = 0; u < kPrepBatch; ++u) {
-            const uint32_t i = m_j + u;
-            d5[u] = i + 5 <= Lq; d9[u] = i + seedk <= Lq; d13[u] = i >= trg0 && i + mink <= Lq;
-            uint32_t code = 0;
-            const uint32_t kk = d13[u] ? mink : d9[u] ? seedk : d5[u] ? 5u : 0u;
-            uint32_t c5 = 0, c9 = 0;
-            for(uint32_t t = 0; t < kk; ++t) {
-                code = (code << 2) | qq[i + t];
-                if(t == 4) c5 = code;
-                if(t + 1 == seedk) c9 = code;
-            }
-            if(d5[u]) table_entry(t5, c5, e5[u]);
-            if(d9[u]) table_entry(t9, c9, e9[u]);
-            if(d13[u]) table_entry(t13, code, e13[u]);
+        const uint32_t i0 = m_j;
+        // the characters the batch's k-mers cover, fetched once (independent byte loads), as one 2-bit string
+        uint64_t bits = 0;                                        // character i0 + t at bits [2t, 2t + 2)
+        {
+            const uint32_t nch = i0 + kPrepBatch + mink - 1 <= Lq ? kPrepBatch + mink - 1 : (Lq > i0 ? Lq - i0 : 0u);
+            uint8_t ch[kPrepBatch + 15];
+#pragma unroll
+            for(uint32_t t = 0; t < kPrepBatch + 15; ++t) ch[t] = t < nch ? qq[i0 + t] : (uint8_t)0;
+#pragma unroll
+            for(uint32_t t = 0; t < kPrepBatch + 15; ++t) bits |= (uint64_t)(ch[t] & 3u) << (2 * t);
         }
-        for(uint32_t u = 0; u < kPrepBatch; ++u) {
-            const uint32_t i = m_j + u;
-            if(d5[u]) flags5()[i] = (uint8_t)((e5[u][0] <= e5[u][1] ? 1 : 0) | (e5[u][2] <= e5[u][3] ? 2 : 0));
-            if(d9[u]) {
-                SortItem* a = it9f() + i; SortItem* b = it9r() + i;
-                a->key = e9[u][0] <= e9[u][1] ? (uint64_t)e9[u][0] : kNoKey; a->val = i; a->pad = 0;
-                b->key = e9[u][2] <= e9[u][3] ? (uint64_t)e9[u][2] : kNoKey; b->val = i; b->pad = 0;
+        // codes of the kk-mers at offsets i0 .. i0 + 15 (first character in the high bits = the table index), rolling
+        uint32_t c5s[kPrepBatch], c9s[kPrepBatch], c13s[kPrepBatch];
+        {
+            uint32_t c5v = 0, c9v = 0, c13v = 0;
+            const uint32_t m5 = (1u << 10) - 1u, m9 = (1u << (2 * seedk)) - 1u, m13 = mink >= 16 ? 0xFFFFFFFFu : (1u << (2 * mink)) - 1u;
+            for(uint32_t t = 0; t + 1 < 5; ++t) c5v = (c5v << 2) | (uint32_t)((bits >> (2 * t)) & 3u);
+            for(uint32_t t = 0; t + 1 < seedk; ++t) c9v = (c9v << 2) | (uint32_t)((bits >> (2 * t)) & 3u);
+            for(uint32_t t = 0; t + 1 < mink; ++t) c13v = (c13v << 2) | (uint32_t)((bits >> (2 * t)) & 3u);
+#pragma unroll
+            for(uint32_t u = 0; u < kPrepBatch; ++u) {
+                c5v = ((c5v << 2) | (uint32_t)((bits >> (2 * (u + 4))) & 3u)) & m5;
+                c9v = ((c9v << 2) | (uint32_t)((bits >> (2 * (u + seedk - 1))) & 3u)) & m9;
+                c13v = ((c13v << 2) | (uint32_t)((bits >> (2 * (u + mink - 1))) & 3u)) & m13;
+                c5s[u] = c5v; c9s[u] = c9v; c13s[u] = c13v;
             }
-            if(d13[u]) {
-                P* t = term() + (uint64_t)(i - trg0) * 4;
-                t[0] = e13[u][0]; t[1] = e13[u][1]; t[2] = e13[u][2]; t[3] = e13[u][3];
-            }
-            n_tab += (d5[u] ? 1u : 0u) + (d9[u] ? 1u : 0u) + (d13[u] ? 1u : 0u);
+        }
+        // pass 1: 5-mers -> per-offset code + strand-validity flags
+        {
+            P e[kPrepBatch][4];
+#pragma unroll
+            for(uint32_t u = 0; u < kPrepBatch; ++u) if(i0 + u + 5 <= Lq) table_entry(t5, c5s[u], e[u]);
+#pragma unroll
+            for(uint32_t u = 0; u < kPrepBatch; ++u)
+                if(i0 + u + 5 <= Lq) { c5()[i0 + u] = (uint16_t)(c5s[u] | (e[u][0] <= e[u][1] ? 0x400u : 0u) | (e[u][2] <= e[u][3] ? 0x800u : 0u)); n_tab += 1; }
+        }
+        // pass 2: idmers -> the two sort arrays
+        {
+            P e[kPrepBatch][4];
+#pragma unroll
+            for(uint32_t u = 0; u < kPrepBatch; ++u) if(i0 + u + seedk <= Lq) table_entry(t9, c9s[u], e[u]);
+#pragma unroll
+            for(uint32_t u = 0; u < kPrepBatch; ++u)
+                if(i0 + u + seedk <= Lq) {
+                    const uint32_t i = i0 + u, code = c9s[u];
+                    SortItem* a = it9f() + i; SortItem* b = it9r() + i;
+                    a->key = e[u][0] <= e[u][1] ? (uint64_t)e[u][0] : kNoKey; a->val = i; a->pad = code;
+                    b->key = e[u][2] <= e[u][3] ? (uint64_t)e[u][2] : kNoKey; b->val = i; b->pad = code;
+                    n_tab += 1;
+                }
+        }
+        // pass 3: minOverlap-mers inside the target seed -> terminal intervals
+        if(i0 + kPrepBatch > trg0) {
+            P e[kPrepBatch][4];
+#pragma unroll
+            for(uint32_t u = 0; u < kPrepBatch; ++u) if(i0 + u >= trg0 && i0 + u + mink <= Lq) table_entry(t13, c13s[u], e[u]);
+#pragma unroll
+            for(uint32_t u = 0; u < kPrepBatch; ++u)
+                if(i0 + u >= trg0 && i0 + u + mink <= Lq) {
+                    P* t = term() + (uint64_t)(i0 + u - trg0) * 4;
+                    t[0] = e[u][0]; t[1] = e[u][1]; t[2] = e[u][2]; t[3] = e[u][3];
+                    n_tab += 1;
+                }
         }
         m_j += kPrepBatch;
         if(m_j >= Lq) pc = PC_BEGIN;
         return true;
     }
-    LRSC_SM void prep_advance()
+    LRSC_SM_NI void prep_advance()
     {
         if(prep_fast()) return;
         const uint32_t seedk = seedSize(), mink = minOverlap();
@@ -1119,16 +1243,15 @@ struct ReadSM {
     }
 
     // set up at kernel start (fresh read, or a read that yielded / was parked in an earlier launch)
-    LRSC_SM void init(const FmIndexDev* fm_, const CorrectArgs* a_, const StrandC<P>* sF_, const StrandC<P>* sR_, uint32_t read_index,
-                      P* ex_, uint32_t ex_stride_)
+    LRSC_SM_NI void init(const FmIndexDev* fm_, const CorrectArgs* a_, const StrandC<P>* sF_, const StrandC<P>* sR_, uint32_t read_index)
     {
-        fm = fm_; A = a_; sFp = sF_; sRp = sR_; r = read_index; ex = ex_; ex_stride = ex_stride_;
-        const ReadWork& rw = A->work[r];
-        ReadOut& R = A->out[r];
-        rs = A->read_off[r];
-        n_seeds = A->seed_count[r];
+        fm = fm_; A = a_; sFp = sF_; sRp = sR_; r = read_index;
+        const ReadWork& rw = LRSC_A.work[r];
+        ReadOut& R = LRSC_A.out[r];
+        rs = LRSC_A.read_off[r];
+        n_seeds = LRSC_A.seed_count[r];
         lq_max = rw.lq_max; pathw = rw.pathw;
-        ws = A->workspace + rw.ws_off;
+        ws = LRSC_A.workspace + rw.ws_off;
         const uint8_t* read = this->read();
         const int32_t* seeds = this->seeds();
         uint8_t* out = this->out();
@@ -1138,7 +1261,7 @@ struct ReadSM {
         error = 0; state = kReadDone; walks_here = 0; next = 0; firstType = 0;
         out_len = 0; n_pieces = 0; steps = 0;
         S_seedLen = 0; S_end = 0; S_endBest = 0; S_maxFixed = 0; S_isRepeat = false; it = 1;
-        const bool resume = A->resume != 0;
+        const bool resume = LRSC_A.resume != 0;
         if(resume) {
             out_len = R.out_len; n_pieces = R.n_pieces; steps = (uint32_t)R.steps;
         } else {
@@ -1159,12 +1282,12 @@ struct ReadSM {
             it = R.it;
             if(R.state == kReadParked) {
                 // correctByMSAlignment's tail (:237-244) with the DP stage's answer for target = *iterTarget
-                const uint32_t di = A->dp_index[r];
-                const DpMsaOut m = A->dp_msa[di];
+                const uint32_t di = LRSC_A.dp_index[r];
+                const DpMsaOut m = LRSC_A.dp_msa[di];
                 const int32_t* T0 = seeds + (uint64_t)it * kSeedInts;
                 if(m.error) error = LRSC_WALK_ERR_DP;
                 else if(m.n_rows > 3) {
-                    const uint8_t* cons = A->dp_cons + A->dp_reqs[di].cons_off;
+                    const uint8_t* cons = LRSC_A.dp_cons + LRSC_A.dp_reqs[di].cons_off;
                     if(m.cons_len < R.dp_k) error = LRSC_WALK_ERR_DP;              // out.erase(0, k) would throw in the reference
                     else {
                         const uint32_t appended = m.cons_len - R.dp_k;
@@ -1178,7 +1301,7 @@ struct ReadSM {
                             S_seedLen += (int)appended;
                         }
                     }
-                } else if(A->split) {
+                } else if(LRSC_A.split) {
                     if(out_len + (uint32_t)T0[1] > out_cap()) error = LRSC_WALK_ERR_OUTPUT;
                     else {
                         piece_start[n_pieces++] = out_len;
@@ -1206,10 +1329,10 @@ struct ReadSM {
     LRSC_SM bool wants_setup() const { return pc == PC_NEXT; }
 
     // between walks: end of the chain, budget, or the next walk's geometry + m_query (:163-184)
-    LRSC_SM void next_walk(bool setup_now)
+    LRSC_SM_NI void next_walk(bool setup_now)
     {
         if(!(it < n_seeds) || error) { pc = PC_FINAL; return; }
-        if(next == 0 && A->max_walks != 0 && (walks_here >= A->max_walks || steps - steps0 >= A->max_steps)) {
+        if(next == 0 && LRSC_A.max_walks != 0 && (walks_here >= LRSC_A.max_walks || steps - steps0 >= LRSC_A.max_steps)) {
             state = kReadYield; pc = PC_FINAL; return;
         }
         if(!setup_now) return;
@@ -1224,11 +1347,11 @@ struct ReadSM {
         k = (S_endBest < T[4] ? S_endBest : T[4]) - 2;                     // min(source.endBest, target.startBest) - 2
         if(S_isRepeat || T_isRepeat) {
             k = S_seedLen < T_len ? S_seedLen : T_len;
-            k = k < A->start_kmer_len + 2 ? k : A->start_kmer_len + 2;
+            k = k < LRSC_A.start_kmer_len + 2 ? k : LRSC_A.start_kmer_len + 2;
         }
         rtou = S_isRepeat && !T_isRepeat;
         trg_len = rtou ? k : T_len;
-        if(k < (int)A->seed_size || k > (int)kMaxInitK || k > S_seedLen || interval < 0 || trg_len < (int)A->min_overlap ||
+        if(k < (int)LRSC_A.seed_size || k > (int)kMaxInitK || k > S_seedLen || interval < 0 || trg_len < (int)LRSC_A.min_overlap ||
            (uint32_t)(k + interval + trg_len) > lq_max) { error = LRSC_WALK_ERR_GEOMETRY; pc = PC_FINAL; return; }
         Lq = (uint32_t)(k + interval + trg_len);
         uint8_t* qq = q();
@@ -1245,7 +1368,7 @@ struct ReadSM {
         }
         initk = (uint32_t)k;
         maxOverlap = (uint32_t)k + 2;
-        const int min_SA = A->pb_coverage > 60 ? (int)((A->pb_coverage / 60) * 3) : 3;
+        const int min_SA = LRSC_A.pb_coverage > 60 ? (int)((LRSC_A.pb_coverage / 60) * 3) : 3;
         min_SA_threshold = (uint64_t)min_SA;
         if(interval > 100) maxIndelSize = (uint64_t)(interval * 0.2); else maxIndelSize = 20;
         maxLength = (uint64_t)((1.2 * (interval + 10)) + (double)(2 * (uint64_t)k));
@@ -1255,7 +1378,7 @@ struct ReadSM {
     }
 
     // the walk is over: stitch its result or fall back (:185-206, :119-149)
-    LRSC_SM void walk_end()
+    LRSC_SM_NI void walk_end()
     {
         uint32_t plen = 0, mi = 0;
         uint32_t* bestw = best();
@@ -1270,7 +1393,7 @@ struct ReadSM {
         const uint8_t* qq = q();
         if(code > 0) {
             // merged = path + target.substr(i + minOverlap); out = merged (un-reversed) minus its first k characters
-            const uint32_t tail_from = mi + A->min_overlap;
+            const uint32_t tail_from = mi + LRSC_A.min_overlap;
             const uint32_t tlen = (uint32_t)trg_len - tail_from;
             const uint32_t M = plen + tlen;
             uint32_t appended = 0;
@@ -1308,7 +1431,7 @@ struct ReadSM {
             pc = PC_NEXT;
             return;
         }
-        if(next + 1 < A->next_target && it + (uint32_t)next + 1 < n_seeds) { next++; pc = PC_NEXT; return; }
+        if(next + 1 < LRSC_A.next_target && it + (uint32_t)next + 1 < n_seeds) { next++; pc = PC_NEXT; return; }
         switch(firstType) {
             case -1: ctr(4)++; break;
             case -2: ctr(5)++; break;
@@ -1318,14 +1441,14 @@ struct ReadSM {
         if(error) { pc = PC_FINAL; return; }
         ctr(3)++;
         const int32_t* T0 = seeds + (uint64_t)it * kSeedInts;               // target = *iterTarget
-        if(!A->no_dp) {
+        if(!LRSC_A.no_dp) {
             // correctByMSAlignment (:208-236): park the read with its query = src k-mer + raw segment + target seed
-            ReadOut& R = A->out[r];
+            ReadOut& R = LRSC_A.out[r];
             const int iv0 = T0[0] - S_end - 1;
             int k0 = (S_endBest < T0[4] ? S_endBest : T0[4]) - 2;
             if(S_isRepeat || (T0[3] & 1)) {
                 k0 = S_seedLen < T0[1] ? S_seedLen : T0[1];
-                k0 = k0 < A->start_kmer_len + 2 ? k0 : A->start_kmer_len + 2;
+                k0 = k0 < LRSC_A.start_kmer_len + 2 ? k0 : LRSC_A.start_kmer_len + 2;
             }
             if(k0 < 1 || k0 > S_seedLen || k0 > T0[1] || iv0 < 0 || (uint32_t)(k0 + iv0 + T0[1]) > lq_max) { error = LRSC_WALK_ERR_GEOMETRY; pc = PC_FINAL; return; }
             uint8_t* dq = dpq();
@@ -1339,7 +1462,7 @@ struct ReadSM {
             pc = PC_FINAL;
             return;
         }
-        if(A->split) {
+        if(LRSC_A.split) {
             if(out_len + (uint32_t)T0[1] > out_cap()) { error = LRSC_WALK_ERR_OUTPUT; pc = PC_FINAL; return; }
             piece_start[n_pieces++] = out_len;                               // pieceVec.push_back(target)
             { copy_codes(out + out_len, read + T0[0], (uint32_t)T0[1]); out_len += (uint32_t)T0[1]; }
@@ -1357,13 +1480,13 @@ struct ReadSM {
         pc = PC_NEXT;
     }
 
-    LRSC_SM void finalize()
+    LRSC_SM_NI void finalize()
     {
-        ReadOut& R = A->out[r];
+        ReadOut& R = LRSC_A.out[r];
         R.steps = steps;
         R.it = it; R.s_seed_len = S_seedLen; R.s_end = S_end; R.s_end_best = S_endBest; R.s_max_fixed = S_maxFixed;
         R.s_is_repeat = S_isRepeat ? 1 : 0;
-        R.c[0] = (int64_t)(A->read_off[r + 1] - rs); R.c[2] = n_seeds;
+        R.c[0] = (int64_t)(LRSC_A.read_off[r + 1] - rs); R.c[2] = n_seeds;
         R.n_pieces = n_pieces; R.out_len = out_len; R.merge = n_pieces != 0; R.error = error;
         R.state = error ? kReadDone : state;
         pc = PC_DONE;
@@ -1373,19 +1496,30 @@ struct ReadSM {
     // one sweep: consume the answered request (if any), then run forward through the blocks until the next request
     // =========================================================================================================
     // lanes inside the extension loop of a walk (the population the step gate is a quorum of)
-    LRSC_SM bool in_walk() const { return (pc >= PC_FS && pc <= PC_STEP_ENTRY) || pc == PC_ATT_ENTRY || pc == PC_ATT_LEAF; }
+    LRSC_SM bool in_walk() const { return ((pc >= PC_FS && pc <= PC_STEP_ENTRY) || pc == PC_ATT_ENTRY || pc == PC_ATT_LEAF) && pc != PC_PRUNE_SLOW; }
     // ... of which: waiting at the gate in front of the memory-heavy blocks (acceptance ladder + children, pruning + commit)
-    LRSC_SM bool at_gate() const { return pc == PC_EXT_READY || pc == PC_PRUNE; }
+    LRSC_SM bool at_gate() const { return pc == PC_EXT_READY || pc == PC_PRUNE || pc == PC_ATT_ENTRY; }
+    LRSC_SM bool at_slow_gate() const { return pc == PC_PRUNE_SLOW; }
     LRSC_SM bool in_prep() const { return pc == PC_PREP; }
 
     // One sweep: consume the answered request (if any), then run forward through the blocks until the next request.
     //   setup_now  the set-up quorum is met: lanes between walks build their next m_query and start PREP
     //   begin_now  no lane of the wavefront is in PREP any more: lanes waiting with a finished PREP build their chains
     //              (sort) and root together
+    //   slow_now   the slow gate is open (general commits of wide frontiers, batched over several steps)
     //   gate_now   the step gate is open: lanes at the gate run the memory-heavy blocks together, so that their
     //              dependent workspace accesses overlap instead of each lane paying its own latency in its own sweep
-    LRSC_SM void sweep(bool have_result, const SmReq<P>& res, bool setup_now, bool begin_now, bool gate_now)
+    // tk: optional per-block tick accumulators (profiling build of the kernel passes them; nullptr otherwise)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LRSC_SM_TICK() (tk ? (uint64_t)__builtin_readcyclecounter() : 0ull)
+#else
+#define LRSC_SM_TICK() 0ull
+#endif
+#define LRSC_SM_ACC(i) do { if(tk) { const uint64_t t_now = LRSC_SM_TICK(); tk[i] += t_now - t_prev; t_prev = t_now; } } while(0)
+    LRSC_SM void sweep(bool have_result, const SmReq<P>& res, bool setup_now, bool begin_now, bool gate_now, bool slow_now, P* ex_, uint32_t ex_stride_, uint64_t* tk = nullptr)
     {
+        uint64_t t_prev = LRSC_SM_TICK();
+        tkp = tk;
         req.kind = kReqNone;
         if(have_result) {
             if(pc == PC_FS) fs_result(res);
@@ -1398,20 +1532,30 @@ struct ReadSM {
             root.kmerFrequency = (int)(isize(root.flo, root.fhi) + isize(root.rlo, root.rhi));
             pc = PC_STEP_ENTRY;
         }
-        if(pc == PC_EXT_READY && gate_now) ext_eval();
+        LRSC_SM_ACC(0);                                            // results of FS / SF / PREP requests
+        if(pc == PC_EXT_READY && gate_now) ext_eval(ex_, ex_stride_);
+        LRSC_SM_ACC(1);
         if(pc == PC_ATT_DONE) att_done();
         if(pc == PC_AFTER_SF_A) { att_no = 2; fs_begin(0, n_cur, (uint32_t)sf_result, PC_ATT_ENTRY, true); }
         if(pc == PC_POST) post();
         if(pc == PC_AFTER_SF_B) fs_begin(1, n_nxt, (uint32_t)sf_result, PC_PRUNE, true);
-        if(pc == PC_PRUNE && gate_now) prune_and_commit();
+        LRSC_SM_ACC(2);
+        if(pc == PC_PRUNE && gate_now && !prune_is_simple()) pc = PC_PRUNE_SLOW;
+        if((pc == PC_PRUNE && gate_now) || (pc == PC_PRUNE_SLOW && slow_now)) prune_and_commit();
+        LRSC_SM_ACC(3);
         if(pc == PC_STEP_ENTRY) step_entry();
+        LRSC_SM_ACC(4);
         if(pc == PC_WALK_END) walk_end();
         if(pc == PC_NEXT) next_walk(setup_now);
+        LRSC_SM_ACC(5);
         if(pc == PC_PREP && req.kind == kReqNone) prep_advance();
+        LRSC_SM_ACC(6);
         if(pc == PC_BEGIN && begin_now) begin_walk();
-        if(pc == PC_ATT_ENTRY) att_entry();
+        LRSC_SM_ACC(7);
+        if(pc == PC_ATT_ENTRY && gate_now) att_entry();
         if(pc == PC_ATT_LEAF) att_leaf();
         if(pc == PC_FINAL) finalize();
+        LRSC_SM_ACC(8);
     }
 };
 

@@ -163,16 +163,16 @@ static int run_emul(EmulIndex* ix, const lrsc_params& p, const uint8_t* codes, c
         a.dp_index = dp_index.data(); a.dp_reqs = reqs.data(); a.dp_msa = msa.data(); a.dp_cons = cons.data();
         for(uint32_t r : todo) {
             ReadSM<WIDE> L;
-            L.n_rank = L.n_blk = L.n_tab = 0;
+            L.n_rank = L.n_blk = L.n_tab = 0; L.tkp = nullptr;
             P ex[16];
-            L.init(&ix->dev, &a, &sF, &sR, r, ex, 1);
+            L.init(&ix->dev, &a, &sF, &sR, r);
             SmReq<P> res{};
             uint64_t guard = 0;
             while(L.pc != PC_DONE) {
                 const bool have = L.req.kind != kReqNone;
                 if(have) { sm_answer<WIDE>(ix->dev, sF, sR, ix->mtab.data(), L.req, res, ex, 1, L.n_rank, L.n_blk, L.n_tab); ++requests; }
                 if(g_trace && launches == 1 && r == g_trace_read) sm_trace<P>(g_trace, g_trace_cap, g_trace_pos, L.pc, have, L.req, res);
-                L.sweep(have, res, true, true, true);
+                L.sweep(have, res, true, true, true, true, ex, 1);
                 ++sweeps;
                 if(++guard > (1ull << 34)) return -2;
             }
