@@ -72,7 +72,11 @@ def main():
     ap.add_argument("--reads", type=int, default=100_000, help="reads per GPU (= index reads on rank 0)")
     ap.add_argument("--read-len", type=int, default=10_000)
     ap.add_argument("--reads-per-step", type=int, default=0,
-                    help="reads of one step's resident sub-batch (0 = stage default: all reads for `seeds`, 25000 otherwise)")
+                    help="reads of one step's resident sub-batch (0 = stage default: all reads for `seeds`; 28000 otherwise, so that the driver's ""--steps 20 --warmup 5 fits its 600 s: a correct step is latency-bound, see DESIGN.md section 4)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="correct stages: a step's sub-batch is cut into this many parts, corrected concurrently by one host thread + "
+                         "ctx (HIP stream) each, so that the DP rounds of one part overlap the extension of the others "
+                         "(default 1: on one GPU the parts contend for the same wavefront slots and the step gets slower)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 disables it and parity_sample)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="oracle threads of the cpu_baseline leg (0 = all host cores of this process)")
     ap.add_argument("--stage", choices=list(STAGE_INFO), default="correct",
@@ -137,43 +141,66 @@ def main():
     else:
         bases, off = api.synth_reads(0x5EED0002, genome, n_reads, args.read_len,
                                      first_read=lrdist.weak_shard_first_read(rank, n_reads))
-    per_step = args.reads_per_step or (n_reads if args.stage == "seeds" else 25_000)
+    per_step = args.reads_per_step or (n_reads if args.stage == "seeds" else 28_000)
     per_step = max(1, min(per_step, n_reads))
+    n_streams = 1 if args.stage == "seeds" else max(1, args.streams or 1)
     cuts = list(range(0, n_reads, per_step)) + [n_reads]
     if len(cuts) > 2 and cuts[-1] - cuts[-2] < per_step // 2:      # fold a short last sub-batch into the one before it
         del cuts[-2]
-    batches, batch_bases = [], []
+    ctxs = [ctx] + [index.ctx(params, local_rank) for _ in range(n_streams - 1)]
+    groups, group_bases = [], []          # one group per step: n_streams resident parts, one per ctx
     for lo, hi in zip(cuts[:-1], cuts[1:]):
-        sub_off = (off[lo: hi + 1] - off[lo]).astype(np.uint64)
-        batches.append(ctx.batch(bases[int(off[lo]): int(off[hi])], sub_off))
-        batch_bases.append(int(off[hi]) - int(off[lo]))
-    log(f"{len(batches)} sub-batch(es) resident in HBM: {[b.n_reads for b in batches]} reads, {int(off[-1]) / 1e6:.1f} Mbases in all")
+        bounds = [lo + (hi - lo) * j // n_streams for j in range(n_streams + 1)]
+        parts = []
+        for c, plo, phi in zip(ctxs, bounds[:-1], bounds[1:]):
+            sub_off = (off[plo: phi + 1] - off[plo]).astype(np.uint64)
+            parts.append(c.batch(bases[int(off[plo]): int(off[phi])], sub_off))
+        groups.append(parts)
+        group_bases.append(int(off[hi]) - int(off[lo]))
+    batches = [b for g in groups for b in g]
+    reads_per_step = sum(b.n_reads for b in groups[0])
+    log(f"{len(groups)} sub-batch(es) of {reads_per_step} reads resident in HBM ({n_streams} concurrent part(s) each), "
+        f"{int(off[-1]) / 1e6:.1f} Mbases in all")
 
     totals = {"walks": 0, "fm": 0, "dp": 0, "corrected_reads": 0, "corrected_bases": 0}
-    kept = {}            # results of sub-batch 0 from its latest pass (parity_sample compares them with the oracle)
+    kept = {}            # results of part 0 of sub-batch 0 from its latest pass (parity_sample compares them with the oracle)
+
+    def correct_part(g, j, timed, acc):
+        b = groups[g][j]
+        res, poff, out = b.correct()      # FM-extension chain (+ DP/MSA rounds) and stitching on the device; results on the host
+        if timed:
+            acc.append((sum(r.total_walk_num for r in res), sum(r.fm_num for r in res), sum(r.dp_num for r in res),
+                        sum(1 for r in res if r.merge), int(out.size)))
+        if g == 0 and j == 0:
+            kept["res"], kept["poff"], kept["out"] = res, poff.copy(), out.copy()
 
     def step(i, timed):
-        j = i % len(batches)
-        b = batches[j]
-        b.find_seeds()          # k-mer grid (Occ-rank kernel) + getSeqAttribute + greedy seed scan, all on the device
+        g = i % len(groups)
+        # seed stage of every part first, one after the other (each launch has the GPU to itself: the k-mer grid kernel's
+        # HIP-event time in this run is its own), then the parts' correction concurrently
+        for b in groups[g]:
+            b.find_seeds()          # k-mer grid (Occ-rank kernel) + getSeqAttribute + greedy seed scan, all on the device
         if args.stage != "seeds":
-            res, poff, out = b.correct()      # FM-extension chain (+ DP/MSA rounds) and stitching on the device; results on the host
-            if timed:
-                totals["walks"] += sum(r.total_walk_num for r in res)
-                totals["fm"] += sum(r.fm_num for r in res)
-                totals["dp"] += sum(r.dp_num for r in res)
-                totals["corrected_reads"] += sum(1 for r in res if r.merge)
-                totals["corrected_bases"] += int(out.size)
-            if j == 0:
-                kept["res"], kept["poff"], kept["out"] = res, poff.copy(), out.copy()
-        return batch_bases[j]
+            acc = []
+            if n_streams == 1:
+                correct_part(g, 0, timed, acc)
+            else:
+                ths = [threading.Thread(target=correct_part, args=(g, j, timed, acc)) for j in range(n_streams)]
+                for th in ths: th.start()
+                for th in ths: th.join()
+            for a in acc:
+                for key, v in zip(("walks", "fm", "dp", "corrected_reads", "corrected_bases"), a):
+                    totals[key] += v
+        return group_bases[g]
 
     for i in range(args.warmup):
         step(i, False)
-    ctx.stats_reset()
+    for c in ctxs:
+        c.stats_reset()
 
     def fence():
-        ctx.sync()
+        for c in ctxs:
+            c.sync()
         torch.cuda.synchronize()
         lrdist.barrier()
         torch.cuda.synchronize()
@@ -189,8 +216,15 @@ def main():
     # max over ranks of the elapsed time; sum over ranks of the bases processed
     elapsed_max, total_bases = lrdist.combine(elapsed, float(my_bases), device="cpu" if one_device else "cuda")
 
+    class Agg:
+        def __init__(self, which):
+            sts = [c.stats(which) for c in ctxs]
+            self.launches = sum(x.launches for x in sts); self.total_ms = sum(x.total_ms for x in sts)
+            self.block_loads = sum(x.block_loads for x in sts); self.table_loads = sum(x.table_loads for x in sts)
+            self.rank_queries = sum(x.rank_queries for x in sts)
+
     def roofline_of(which, name):
-        st = ctx.stats(which)
+        st = Agg(which)
         launches = max(st.launches, 1)
         ms = st.total_ms / launches
         lines = (st.block_loads + st.table_loads) / launches
@@ -214,14 +248,15 @@ def main():
                 roof["traffic_unit"] = "GB per launch (separate rocprofv3 --pmc passes, corrected as MI355X_MICROARCH.md prescribes)"
                 roof["traffic_source"] = pj["source"]
         value = total_bases / elapsed_max / 1e6
-        st_seeds = ctx.stats(K_SEEDS)
-        stage_ms = {"kmer_grid": ctx.stats(K_GRID).total_ms / args.steps, "seed_scan_group": st_seeds.total_ms / args.steps}
+        stage_ms = {"kmer_grid": Agg(K_GRID).total_ms / args.steps, "seed_scan_group": Agg(K_SEEDS).total_ms / args.steps}
         if args.stage != "seeds":
-            stage_ms.update({"fm_extend_and_stitch": ctx.stats(K_EXTEND).total_ms / args.steps,
-                             "fm_extend_launches_per_step": ctx.stats(K_EXTEND).launches / args.steps,
-                             "dp_retrieve_lf_walks": ctx.stats(K_LF).total_ms / args.steps,
-                             "dp_extend_match": ctx.stats(K_DP).total_ms / args.steps,
-                             "dp_msa_consensus": ctx.stats(K_MSA).total_ms / args.steps})
+            # summed over the concurrent parts: with n_streams > 1 these overlap in time and add up to more than the step
+            stage_ms.update({"fm_extend_and_stitch": Agg(K_EXTEND).total_ms / args.steps,
+                             "fm_extend_launches_per_step": Agg(K_EXTEND).launches / args.steps,
+                             "dp_retrieve_lf_walks": Agg(K_LF).total_ms / args.steps,
+                             "dp_extend_match": Agg(K_DP).total_ms / args.steps,
+                             "dp_msa_consensus": Agg(K_MSA).total_ms / args.steps,
+                             "concurrent_parts": n_streams})
         result = {
             "metric": sinfo["metric"],
             "value": value,
@@ -239,13 +274,15 @@ def main():
                 "workload": (f"BASELINE configs[{sinfo['config']}]: {n_reads} x {args.read_len / 1000:g} kb reads/GPU (15% err: 4.5% del, 1.5% sub, "
                              f"9% ins) over the FM-index of the {n_reads}-read 90x set of a {args.genome_mb:g} Mb genome "
                              f"({n_sym / 1e9:.2f} G symbols/strand), -c 90 -g 5{' --nodp' if args.stage == 'correct-nodp' else ''}; "
-                             f"one step = one resident sub-batch of {batches[0].n_reads} reads ({batch_bases[0] / 1e6:.0f} Mbases) through "
+                             f"one step = one resident sub-batch of {reads_per_step} reads ({group_bases[0] / 1e6:.0f} Mbases"
+                             f"{', corrected as %d concurrent parts' % n_streams if n_streams > 1 else ''}) through "
                              f"{'the seed stage' if args.stage == 'seeds' else 'the whole per-read path, results downloaded'}"),
                 "stage": args.stage,
                 "stages_timed": sinfo["stages"],
                 "stage_ms_per_step": stage_ms,
-                "reads_per_step": batches[0].n_reads,
-                "sub_batches": len(batches),
+                "reads_per_step": reads_per_step,
+                "sub_batches": len(groups),
+                "concurrent_parts_per_step": n_streams,
                 **({} if args.stage == "seeds" else {
                     "walks": totals["walks"], "fm_walks": totals["fm"], "dp_walks": totals["dp"],
                     "corrected_reads": totals["corrected_reads"], "corrected_bases_out": totals["corrected_bases"]}),
@@ -259,7 +296,7 @@ def main():
         if args.stage != "seeds":
             result["roofline_extra"] = [roofline_of(K_EXTEND, "correct_reads_kernel")]
         if world == 1 and args.cpu_seconds > 0:
-            cb, ps = cpu_baseline(units, n_reads, n_sym, params, bases, off, cuts[1], args, kept, batches[0])
+            cb, ps = cpu_baseline(units, n_reads, n_sym, params, bases, off, batches[0].n_reads, args, kept, batches[0])
             result["cpu_baseline"] = cb
             if ps is not None:
                 result["parity_sample"] = ps
@@ -269,7 +306,8 @@ def main():
 
     for b in batches:
         b.close()
-    ctx.close()
+    for c in ctxs:
+        c.close()
     index.close()
     if world > 1:
         dist.destroy_process_group()

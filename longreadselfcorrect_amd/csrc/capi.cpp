@@ -83,7 +83,11 @@ struct DevBuf {
     }
 };
 
+struct CorrectScratch;                                   // device buffers lrsc_batch_correct keeps between calls (defined with it)
+static void free_correct_scratch(CorrectScratch* cs);
+
 struct lrsc_ctx {
+    CorrectScratch* cs = nullptr;
     const lrsc_index* index = nullptr;
     lrsc_params params{};
     int device = 0;
@@ -435,6 +439,7 @@ extern "C" void lrsc_ctx_destroy(lrsc_ctx* ctx)
     if(!ctx) return;
     (void)hipSetDevice(ctx->device);
     if(ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    free_correct_scratch(ctx->cs);
     if(ctx->d_ctr) (void)hipFree(ctx->d_ctr);
     if(ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if(ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -1114,6 +1119,8 @@ struct DpStage {
     DevBuf<uint8_t> d_cons, d_strings, d_ops, d_trace;
     DevBuf<DpJob> d_jobs;
     DevBuf<DpAlignOut> d_align;
+    DevBuf<uint32_t> d_list;
+    DevBuf<uint8_t> d_msa_ws;
     uint64_t cons_total = 0, n_strings = 0;
     // the MSA size buckets of a round run concurrently on side streams (each bucket's launch ends with a tail of a few long
     // pile-ups; serialised, those tails cost more than the work)
@@ -1234,8 +1241,6 @@ struct DpStage {
             std::vector<DpMsaOut> mo(nc);
             std::vector<uint32_t> todo(nc), list;
             for(uint32_t i = 0; i < nc; ++i) todo[i] = i;
-            DevBuf<uint32_t> d_list;
-            DevBuf<uint8_t> d_msa_ws;
             HIP_TRY(d_list.reserve(nc));
             while(!todo.empty()) {
                 static const uint32_t kBuckets[] = {8u << 10, 12u << 10, 16u << 10, 24u << 10, 40u << 10, 80u << 10, 160u << 10, 0xFFFFFFFFu};
@@ -1321,6 +1326,32 @@ struct DpStage {
     }
 };
 
+// Device buffers of lrsc_batch_correct, kept in the ctx between calls (grow-only): hipMalloc / hipFree synchronise the whole
+// device, which serialises contexts that correct sub-batches concurrently on one GPU and costs every call of a loop.
+struct CorrectScratch {
+    DevBuf<ReadPlan> d_plan;
+    DevBuf<ReadWork> d_work;
+    DevBuf<ReadOut> d_out;
+    DevBuf<uint32_t> d_order, d_pieces, d_queue, d_dp_index, d_parked, d_yielded, d_trace;
+    DevBuf<uint8_t> d_ws, d_codes_out;
+    DevBuf<uint64_t> d_dst_off;
+    DevBuf<char> d_dst;
+    DevBuf<double> d_freqs;
+    DevBuf<CorrectArgs> d_args;
+    DevBuf<FmIndexDev> d_fm;
+    DevBuf<unsigned long long> d_prof;
+    DpStage stage;
+    hipStream_t ystream = nullptr;
+    hipEvent_t y0 = nullptr, y1 = nullptr;
+    ~CorrectScratch()
+    {
+        if(ystream) { (void)hipStreamSynchronize(ystream); (void)hipStreamDestroy(ystream); }
+        if(y0) (void)hipEventDestroy(y0);
+        if(y1) (void)hipEventDestroy(y1);
+    }
+};
+static void free_correct_scratch(CorrectScratch* cs) { delete cs; }
+
 // ---------------------------------------------------------------------------------------
 // the whole per-read path on the device
 // ---------------------------------------------------------------------------------------
@@ -1353,14 +1384,17 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
     for(int i = p.min_kmer_len; i <= 100; i++) freqs[i] = pow(1 - p.error_rate, i) * (size_t)p.pb_coverage;
 
     // ---- plan: per-read walk bounds from the device-resident seeds ---------------------------------------
-    DevBuf<ReadPlan> d_plan;
-    DevBuf<ReadWork> d_work;
-    DevBuf<ReadOut> d_out;
-    DevBuf<uint32_t> d_order, d_pieces;
-    DevBuf<uint8_t> d_ws, d_codes_out;
-    DevBuf<uint64_t> d_dst_off;
-    DevBuf<char> d_dst;
-    DevBuf<double> d_freqs;
+    if(!ctx->cs) ctx->cs = new(std::nothrow) CorrectScratch();
+    if(!ctx->cs) return fail(LRSC_ERR_NOMEM, "correct scratch");
+    CorrectScratch& cs = *ctx->cs;
+    DevBuf<ReadPlan>& d_plan = cs.d_plan;
+    DevBuf<ReadWork>& d_work = cs.d_work;
+    DevBuf<ReadOut>& d_out = cs.d_out;
+    DevBuf<uint32_t>&d_order = cs.d_order, &d_pieces = cs.d_pieces;
+    DevBuf<uint8_t>&d_ws = cs.d_ws, &d_codes_out = cs.d_codes_out;
+    DevBuf<uint64_t>& d_dst_off = cs.d_dst_off;
+    DevBuf<char>& d_dst = cs.d_dst;
+    DevBuf<double>& d_freqs = cs.d_freqs;
     HIP_TRY(d_plan.reserve(n));
     HIP_TRY(d_work.reserve(n));
     HIP_TRY(d_out.reserve(n));
@@ -1448,7 +1482,7 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
     // max_walks walks instead of as long as the luckiest read's failure-free stretch, and parked reads get their answer sooner.
     // LRSC_CORRECT_QUEUE=k (experimental): launch 1/k of the lanes and let every lane pull reads from a queue.  Off: with 100k
     // reads it trades resident wavefronts for lane refill and loses (39.9 - 46.6 s vs 32.2 s per Gbase, default flow).
-    DevBuf<uint32_t> d_queue;
+    DevBuf<uint32_t>& d_queue = cs.d_queue;
     uint32_t queue_rpl = 0;
     if(const char* e = std::getenv("LRSC_CORRECT_QUEUE")) queue_rpl = (uint32_t)std::max(0, std::atoi(e));
     if(queue_rpl) HIP_TRY(d_queue.reserve(1));
@@ -1464,8 +1498,8 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
     const char* kern_env = std::getenv("LRSC_CORRECT_KERNEL");
     const bool use_sm = kern_env && std::strcmp(kern_env, "sm") == 0;
     constexpr uint32_t kArgSlots = 16;
-    DevBuf<CorrectArgs> d_args;
-    DevBuf<FmIndexDev> d_fm;
+    DevBuf<CorrectArgs>& d_args = cs.d_args;
+    DevBuf<FmIndexDev>& d_fm = cs.d_fm;
     uint32_t arg_slot = 0;
     if(use_sm) {
         HIP_TRY(d_args.reserve(kArgSlots));
@@ -1493,7 +1527,7 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
     if(const char* e = std::getenv("LRSC_CORRECT_MAX_WALKS")) a.max_walks = (uint32_t)std::max(0, std::atoi(e));
     if(const char* e = std::getenv("LRSC_CORRECT_MAX_STEPS")) a.max_steps = (uint32_t)std::max(1, std::atoi(e));
     // LRSC_SM_TRACE=<file>: debugging aid, per-sweep trace of read LRSC_SM_TRACE_READ (first launch only)
-    DevBuf<uint32_t> d_trace;
+    DevBuf<uint32_t>& d_trace = cs.d_trace;
     const char* trace_file = std::getenv("LRSC_SM_TRACE");
     if(trace_file && use_sm) {
         a.trace_cap = 14u * 400000u + 1u;
@@ -1503,7 +1537,7 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
         a.trace_read = std::getenv("LRSC_SM_TRACE_READ") ? (uint32_t)std::atoi(std::getenv("LRSC_SM_TRACE_READ")) : 0u;
     }
     // LRSC_SM_PROFILE=1: per-wavefront tick totals of the state-machine kernel's sweep classes (first launch), on stderr
-    DevBuf<unsigned long long> d_prof;
+    DevBuf<unsigned long long>& d_prof = cs.d_prof;
     uint32_t prof_waves = 0;
     if(std::getenv("LRSC_SM_PROFILE") && use_sm) {
         prof_waves = (n + a.reads_per_wave - 1) / a.reads_per_wave;
@@ -1546,8 +1580,8 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
     std::vector<ReadOut> ro(n);
     HIP_TRY(hipMemcpy(ro.data(), d_out.p, (size_t)n * sizeof(ReadOut), hipMemcpyDeviceToHost));
     if(!p.no_dp || a.max_walks != 0) {
-        DpStage stage;
-        DevBuf<uint32_t> d_dp_index, d_parked, d_yielded;
+        DpStage& stage = cs.stage;
+        DevBuf<uint32_t>&d_dp_index = cs.d_dp_index, &d_parked = cs.d_parked, &d_yielded = cs.d_yielded;
         std::vector<uint32_t> parked, yielded, dp_index(n, 0);
         std::vector<DpRequest> reqs;
         HIP_TRY(d_dp_index.reserve(n));
@@ -1556,12 +1590,12 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
         // LRSC_CORRECT_OVERLAP=1: reads that only used up their step budget go on at once, on a side stream, while the DP stage
         // answers the parked ones.  Off by default: measured 48.0 s vs 44.1 s per Gbase -- the correction kernel is issue-bound
         // at full load, two concurrent launches only add a second tail.
-        hipStream_t ystream = nullptr;
-        hipEvent_t y0 = nullptr, y1 = nullptr;
-        HIP_TRY(hipStreamCreateWithFlags(&ystream, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreate(&y0));
-        HIP_TRY(hipEventCreate(&y1));
-        struct SideGuard { hipStream_t s; hipEvent_t a, b; ~SideGuard() { (void)hipStreamSynchronize(s); (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipStreamDestroy(s); } } guard{ystream, y0, y1};
+        if(!cs.ystream) HIP_TRY(hipStreamCreateWithFlags(&cs.ystream, hipStreamNonBlocking));
+        if(!cs.y0) HIP_TRY(hipEventCreate(&cs.y0));
+        if(!cs.y1) HIP_TRY(hipEventCreate(&cs.y1));
+        hipStream_t ystream = cs.ystream;
+        hipEvent_t y0 = cs.y0, y1 = cs.y1;
+        struct SideGuard { hipStream_t s; ~SideGuard() { (void)hipStreamSynchronize(s); } } guard{ystream};
         const bool overlap = std::getenv("LRSC_CORRECT_OVERLAP") != nullptr;
         for(uint32_t round = 0;; ++round) {
             parked.clear(); yielded.clear(); reqs.clear();

@@ -2,6 +2,7 @@
 // (PacBio/PacBioSelfCorrectionProcess.cpp:250-380: FASTA records and the statistics block on stdout).
 #include "PacBioSelfCorrectionProcess.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <iostream>
 #include <thread>
@@ -16,89 +17,71 @@ static void orDie(int st, const char* what)
     }
 }
 
-PacBioSelfCorrectionProcess::PacBioSelfCorrectionProcess(const PacBioSelfCorrectionParameters& params) : m_params(params)
+PacBioSelfCorrectionProcess::PacBioSelfCorrectionProcess(const PacBioSelfCorrectionParameters& params, size_t worker) : m_params(params)
 {
-    for(int d : m_params.devices) {
-        lrsc_ctx* ctx = nullptr;
-        orDie(lrsc_ctx_create(m_params.index, &m_params.p, d, &ctx), "lrsc_ctx_create");
-        m_ctx.push_back(ctx);
-    }
+    const int device = m_params.devices[worker % m_params.devices.size()];
+    orDie(lrsc_ctx_create(m_params.index, &m_params.p, device, &m_ctx), "lrsc_ctx_create");
 }
 
 PacBioSelfCorrectionProcess::~PacBioSelfCorrectionProcess()
 {
-    for(lrsc_ctx* c : m_ctx) lrsc_ctx_destroy(c);
+    lrsc_ctx_destroy(m_ctx);
 }
 
-namespace {
-struct Shard {
-    size_t first = 0, count = 0;
-    std::string bases, out;
-    std::vector<uint64_t> off, pieceOff;
-    std::vector<lrsc_read_result> res;
-    int status = LRSC_OK;
-    std::string error;
-};
+// f(lo, hi) over [0, n) on up to `threads` host threads
+template <class F>
+static void parallelFor(size_t n, int threads, F f)
+{
+    const size_t t = std::max<size_t>(1, std::min<size_t>((size_t)std::max(threads, 1), n / 256 + 1));
+    if(t == 1) { f((size_t)0, n); return; }
+    std::vector<std::thread> th;
+    for(size_t i = 1; i < t; ++i) th.emplace_back(f, n * i / t, n * (i + 1) / t);
+    f((size_t)0, n / t);
+    for(std::thread& x : th) x.join();
 }
 
 std::vector<PacBioSelfCorrectionResult> PacBioSelfCorrectionProcess::process_batch(const std::vector<SequenceWorkItem>& items)
 {
-    // contiguous input-order chunks, one per device; each device has its own ctx
-    const size_t nd = m_ctx.size();
-    std::vector<Shard> shards(nd);
-    const size_t per = (items.size() + nd - 1) / nd;
-    for(size_t d = 0; d < nd; ++d) {
-        Shard& s = shards[d];
-        s.first = std::min(items.size(), d * per);
-        s.count = std::min(items.size(), (d + 1) * per) - s.first;
-        s.off.assign(1, 0);
-        for(size_t i = 0; i < s.count; ++i) {
-            s.bases += items[s.first + i].read.seq;
-            s.off.push_back(s.bases.size());
-        }
+    const size_t n = items.size();
+    std::vector<PacBioSelfCorrectionResult> results(n);
+    if(n == 0) return results;
+    // the batch as the C ABI takes it: one block of bases + offsets
+    m_off.assign(n + 1, 0);
+    for(size_t i = 0; i < n; ++i) m_off[i + 1] = m_off[i] + items[i].read.seq.size();
+    m_bases.resize(m_off[n]);
+    parallelFor(n, m_params.threads, [&](size_t lo, size_t hi) {
+        for(size_t i = lo; i < hi; ++i) items[i].read.seq.copy(&m_bases[m_off[i]], std::string::npos);
+    });
+    m_res.resize(n);
+    m_pieceOff.resize(std::max<size_t>(m_pieceOff.size(), 2 * n + 16));
+    m_out.resize(std::max<size_t>(m_out.size(), m_bases.size() * 2 + 4096));
+    uint64_t nPieces = 0, used = 0;
+    int st = lrsc_correct_reads(m_ctx, m_bases.data(), m_off.data(), (uint32_t)n, m_res.data(), m_pieceOff.data(), m_pieceOff.size(),
+                                &m_out[0], m_out.size(), &nPieces, &used);
+    if(st == LRSC_ERR_CAPACITY) {
+        m_pieceOff.resize(nPieces + 1);
+        m_out.resize(used);
+        st = lrsc_correct_reads(m_ctx, m_bases.data(), m_off.data(), (uint32_t)n, m_res.data(), m_pieceOff.data(), m_pieceOff.size(),
+                                &m_out[0], m_out.size(), &nPieces, &used);
     }
-    auto run = [&](size_t d) {
-        Shard& s = shards[d];
-        if(s.count == 0) return;
-        s.res.resize(s.count);
-        s.pieceOff.resize(2 * s.count + 16);
-        s.out.resize(s.bases.size() * 2 + 4096);
-        uint64_t nPieces = 0, used = 0;
-        int st = lrsc_correct_reads(m_ctx[d], s.bases.data(), s.off.data(), (uint32_t)s.count, s.res.data(), s.pieceOff.data(),
-                                    s.pieceOff.size(), &s.out[0], s.out.size(), &nPieces, &used);
-        if(st == LRSC_ERR_CAPACITY) {
-            s.pieceOff.resize(nPieces + 1);
-            s.out.resize(used);
-            st = lrsc_correct_reads(m_ctx[d], s.bases.data(), s.off.data(), (uint32_t)s.count, s.res.data(), s.pieceOff.data(),
-                                    s.pieceOff.size(), &s.out[0], s.out.size(), &nPieces, &used);
-        }
-        s.status = st;
-        if(st != LRSC_OK) s.error = lrsc_last_error();
-    };
-    std::vector<std::thread> th;
-    for(size_t d = 1; d < nd; ++d) th.emplace_back(run, d);
-    run(0);
-    for(auto& t : th) t.join();
-
-    std::vector<PacBioSelfCorrectionResult> results(items.size());
-    for(size_t d = 0; d < nd; ++d) {
-        const Shard& s = shards[d];
-        if(s.status != LRSC_OK) {
-            std::cerr << "lrsc_correct_reads: " << lrsc_strerror(s.status) << " (" << s.error << ")\n";
-            exit(EXIT_FAILURE);
-        }
-        for(size_t i = 0; i < s.count; ++i) {
-            const lrsc_read_result& r = s.res[i];
-            PacBioSelfCorrectionResult& o = results[s.first + i];
-            o.readid = items[s.first + i].read.id;
+    if(st != LRSC_OK) {
+        std::cerr << "lrsc_correct_reads: " << lrsc_strerror(st) << " (" << lrsc_last_error() << ")\n";
+        exit(EXIT_FAILURE);
+    }
+    parallelFor(n, m_params.threads, [&](size_t lo, size_t hi) {
+        for(size_t i = lo; i < hi; ++i) {
+            const lrsc_read_result& r = m_res[i];
+            PacBioSelfCorrectionResult& o = results[i];
+            o.readid = items[i].read.id;
             o.merge = r.merge != 0;
             o.totalReadsLen = r.total_reads_len; o.correctedLen = r.corrected_len; o.totalSeedNum = r.total_seed_num;
             o.totalWalkNum = r.total_walk_num; o.highErrorNum = r.high_error_num; o.exceedDepthNum = r.exceed_depth_num;
             o.exceedLeaveNum = r.exceed_leave_num; o.FMNum = r.fm_num; o.DPNum = r.dp_num; o.seedDis = r.seed_dis;
+            o.correctedStrs.reserve(r.n_pieces);
             for(uint64_t p = r.piece_first; p < r.piece_first + r.n_pieces; ++p)
-                o.correctedStrs.push_back(s.out.substr(s.pieceOff[p], s.pieceOff[p + 1] - s.pieceOff[p]));
+                o.correctedStrs.emplace_back(m_out.data() + m_pieceOff[p], m_pieceOff[p + 1] - m_pieceOff[p]);
         }
-    }
+    });
     return results;
 }
 
@@ -110,6 +93,8 @@ PacBioSelfCorrectionResult PacBioSelfCorrectionProcess::process(const SequenceWo
 // ---- post-processor ---------------------------------------------------------------------------------------
 PacBioSelfCorrectionPostProcess::PacBioSelfCorrectionPostProcess(const PacBioSelfCorrectionParameters& params) : m_params(params)
 {
+    m_correct.rdbuf()->pubsetbuf(m_bufCorrect.data(), (std::streamsize)m_bufCorrect.size());
+    m_discard.rdbuf()->pubsetbuf(m_bufDiscard.data(), (std::streamsize)m_bufDiscard.size());
     m_correct.open((m_params.directory + "correct.fa").c_str());
     m_discard.open((m_params.directory + "discard.fa").c_str());
     if(!m_correct || !m_discard) {

@@ -16,6 +16,7 @@ struct PacBioSelfCorrectionParameters {
     lrsc_index* index = nullptr;
     std::vector<int> devices{0};
     std::string directory;
+    int threads = 1;                // -t: host threads that pack a batch's bases and cut the corrected strings out of the device's answer
     lrsc_params p{};                // PBcoverage, ErrorRate, startKmerLen, nextTarget, maxLeaves, idmerLen, minKmerLen, Split, NoDp ...
     bool DebugExtend = false, DebugSeed = false, OnlySeed = false;
 };
@@ -30,16 +31,22 @@ struct PacBioSelfCorrectionResult {
     double Timer_Seed = 0, Timer_FM = 0, Timer_DP = 0;
 };
 
-// Batched processor: one lrsc_ctx per device, contiguous chunks of the batch per device.
+// Batched processor: one instance per device (the framework runs one worker thread per instance and deals whole
+// batches -- contiguous input-order chunks, SURVEY.md section 8e -- to whichever device is free).
 class PacBioSelfCorrectionProcess {
 public:
-    explicit PacBioSelfCorrectionProcess(const PacBioSelfCorrectionParameters& params);
+    explicit PacBioSelfCorrectionProcess(const PacBioSelfCorrectionParameters& params, size_t worker = 0);
     ~PacBioSelfCorrectionProcess();
+    static size_t workers(const PacBioSelfCorrectionParameters& params, int /*thread*/) { return params.devices.size(); }
     std::vector<PacBioSelfCorrectionResult> process_batch(const std::vector<SequenceWorkItem>& items);
     PacBioSelfCorrectionResult process(const SequenceWorkItem& item);     // classic concept (one-item batch)
 private:
     const PacBioSelfCorrectionParameters m_params;
-    std::vector<lrsc_ctx*> m_ctx;
+    lrsc_ctx* m_ctx = nullptr;
+    // staging buffers, kept between batches
+    std::string m_bases, m_out;
+    std::vector<uint64_t> m_off, m_pieceOff;
+    std::vector<lrsc_read_result> m_res;
 };
 
 // PacBioSelfCorrectionPostProcess (reference .cpp:250-380): correct.fa / discard.fa + the stats block
@@ -50,6 +57,7 @@ public:
     void process(const SequenceWorkItem& workItem, const PacBioSelfCorrectionResult& result);
 private:
     const PacBioSelfCorrectionParameters m_params;
+    std::vector<char> m_bufCorrect = std::vector<char>(4u << 20), m_bufDiscard = std::vector<char>(1u << 20);   // stream buffers (declared before the streams)
     std::ofstream m_correct, m_discard;
     int64_t m_totalReadsLen = 0, m_correctedLen = 0, m_totalSeedNum = 0, m_totalWalkNum = 0, m_highErrorNum = 0,
             m_exceedDepthNum = 0, m_exceedLeaveNum = 0, m_FMNum = 0, m_DPNum = 0, m_OutcastNum = 0, m_seedDis = 0;

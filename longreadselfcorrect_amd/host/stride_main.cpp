@@ -190,6 +190,7 @@ static int PacBioSelfCorrectionMain(int argc, char** argv)
     p.split = opt::Split ? 1 : 0; p.no_dp = opt::NoDp ? 1 : 0;
 
     ecParams.index = idx; ecParams.devices = opt::devices; ecParams.directory = opt::directory; ecParams.p = p;
+    ecParams.threads = opt::thread;
 
     {   // <out>/threshold-table (KmerThreshold.cpp:31-41,65-72)
         float thr[3 * 52];
@@ -211,7 +212,7 @@ static int PacBioSelfCorrectionMain(int argc, char** argv)
 
     SequenceProcessFramework::processSequences<SequenceWorkItem, PacBioSelfCorrectionResult, PacBioSelfCorrectionProcess,
                                                PacBioSelfCorrectionPostProcess, PacBioSelfCorrectionParameters>(
-        opt::thread, opt::readsFile, ecParams, opt::batch * opt::devices.size());
+        opt::thread, opt::readsFile, ecParams, opt::batch);
     lrsc_index_close(idx);
     return 0;
 }

@@ -80,11 +80,34 @@ def test_framework_template_keeps_input_order_and_accepts_classic_processors(tmp
     fa.write_text(">a x y\nACGT\nAC\n>b\tz\nacgtt\n@c\nGGG\n+\nIII\n>d\nT\n")
     exe = tmp_path / "fw"
     host = REPO / "longreadselfcorrect_amd" / "host"
-    subprocess.run(["g++", "-std=c++14", "-O1", f"-I{host}", str(src), str(host / "SeqReader.cpp"), "-o", str(exe)], check=True)
+    subprocess.run(["g++", "-std=c++14", "-O1", f"-I{host}", str(src), str(host / "SeqReader.cpp"), "-o", str(exe), "-lz", "-pthread"], check=True)
     out = subprocess.run([str(exe), str(fa)], capture_output=True, text=True, check=True).stdout.split("\n")
     assert out[:5] == ["a 6", "b 5", "c 3", "d 1", "seen 4"]          # multi-line FASTA, upper-casing, FASTQ, ids cut at blank
     assert out[5:10] == ["a 12", "b 10", "c 6", "d 2", "seen 4"]
     assert "ORDER BROKEN" not in out
+
+
+def test_reader_edge_cases_follow_the_reference_rules(tmp_path):
+    """The block parser keeps Util/SeqReader.cpp:26-135's corner cases: junk before the first header is skipped, empty lines inside
+    a FASTA record are skipped, '@' starts a FASTQ record, a last line without a newline is not part of a FASTA record, a FASTQ
+    record whose quality line hits the end of the input is dropped; .gz inputs are inflated (Util/Util.cpp:276-309)."""
+    import gzip
+    src = tmp_path / "rd.cpp"
+    src.write_text('#include <iostream>\n#include "SequenceWorkItem.h"\nint main(int, char** v){ stride::SeqReader r(v[1]); stride::SeqRecord s; '
+                   'while(r.get(s)) std::cout << s.id << " " << s.seq << " " << s.qual << "\\n"; return 0; }\n')
+    host = REPO / "longreadselfcorrect_amd" / "host"
+    exe = tmp_path / "rd"
+    subprocess.run(["g++", "-std=c++14", f"-I{host}", str(src), str(host / "SeqReader.cpp"), "-o", str(exe), "-lz"], check=True)
+
+    def run(name, data):
+        f = tmp_path / name
+        f.write_bytes(data)
+        return subprocess.run([str(exe), str(f)], capture_output=True, text=True, check=True).stdout.split("\n")[:-1]
+
+    assert run("a.fa", b"junk\n>r1 desc\nACGT\nacgt\n\n>r2\tx\nGG\n@q1\nACGT\n+\nIIII\n>r3\nTTTT") == ["r1 ACGTACGT ", "r2 GG ", "q1 ACGT IIII"]
+    assert run("b.fq", b"@q1\nACGT\n+\nIIII\n@q2\nAC\n+\nII") == ["q1 ACGT IIII"]
+    assert run("c.fa.gz", gzip.compress(b">a\nAC\n>b\nGT\n")) == ["a AC ", "b GT "]
+    assert run("d.fa", b"") == [] and run("e.fa", b">only_header\n") == []
 
 
 def test_non_acgt_read_is_fatal_like_the_reference(tmp_path):
@@ -93,7 +116,7 @@ def test_non_acgt_read_is_fatal_like_the_reference(tmp_path):
     fa = tmp_path / "n.fa"
     fa.write_text(">ok\nACGT\n>bad\nACNT\n")
     host = REPO / "longreadselfcorrect_amd" / "host"
-    subprocess.run(["g++", "-std=c++14", f"-I{host}", str(src), str(host / "SeqReader.cpp"), "-o", str(tmp_path / "rd")], check=True)
+    subprocess.run(["g++", "-std=c++14", f"-I{host}", str(src), str(host / "SeqReader.cpp"), "-o", str(tmp_path / "rd"), "-lz"], check=True)
     r = subprocess.run([str(tmp_path / "rd"), str(fa)], capture_output=True, text=True)
     assert r.returncode == 1 and "Error: read bad contains non-ACGT characters." in r.stderr     # Util/SeqReader.cpp:118-123
 
