@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LRSC_ABI_VERSION 1
+#define LRSC_ABI_VERSION 2
 
 typedef enum lrsc_status {
     LRSC_OK = 0,
@@ -234,7 +234,23 @@ typedef struct lrsc_read_result {
     uint64_t piece_first;
     int64_t  total_reads_len, corrected_len, total_seed_num, total_walk_num, high_error_num, exceed_depth_num,
              exceed_leave_num, fm_num, dp_num, seed_dis;
+    int32_t  status;             /* LRSC_READ_OK, or why this one read could not be corrected (the rest of the batch is unaffected):
+                                  * the read then comes back uncorrected (merge = 0, no pieces, counters 0)                 */
+    int32_t  pad;
 } lrsc_read_result;
+/* per-read status: an internal capacity of the device path was exceeded by this read alone.  The reference has no such
+ * bounds (its containers grow); a caller that must not lose the read can route it to a CPU path. */
+enum lrsc_read_status {
+    LRSC_READ_OK = 0,
+    LRSC_READ_WALK_QUERY_TOO_LONG = 1,   /* a walk's query (k-mer + gap between two seeds + target seed) >= 65535 bases  */
+    LRSC_READ_TOO_LONG = 2,              /* the read's output slot would exceed 4 GB                                     */
+    LRSC_READ_FRONTIER_LIMIT = 3,        /* more than 160 terminated lineages / 128 children in one walk                 */
+    LRSC_READ_GEOMETRY = 4,              /* seeds overlap / an extension k-mer above 59 or below the idmer size          */
+    LRSC_READ_DP_LIMIT = 5,              /* DP fallback: query beyond the alignment kernel's staging (about 30 kb), or a pile-up beyond
+                                          * its column / consensus capacity                                              */
+    LRSC_READ_OUTPUT_LIMIT = 6,          /* the corrected string outgrew its slot                                        */
+    LRSC_READ_INTERNAL = 7               /* FM-extension returned a code the reference treats as impossible (it exits)   */
+};
 /* PacBioSelfCorrectionProcess::process for every read of the batch (PacBioSelfCorrectionProcess.cpp:23-206):
  * seeds and seed-to-seed FM-extension on the device, stitching on the host, with the ctx's parameters.
  * Piece p is out[piece_off[p] .. piece_off[p+1]).  Needs params.no_dp (the DP/MSA fallback of

@@ -105,7 +105,7 @@ class MsaResult(C.Structure):
 class ReadResult(C.Structure):
     _fields_ = [("merge", C.c_int32), ("n_pieces", C.c_uint32), ("piece_first", C.c_uint64)] + [
         (n, C.c_int64) for n in ("total_reads_len", "corrected_len", "total_seed_num", "total_walk_num", "high_error_num",
-                                 "exceed_depth_num", "exceed_leave_num", "fm_num", "dp_num", "seed_dis")]
+                                 "exceed_depth_num", "exceed_leave_num", "fm_num", "dp_num", "seed_dis")] + [("status", C.c_int32), ("pad", C.c_int32)]
 
 
 class KernelStats(C.Structure):

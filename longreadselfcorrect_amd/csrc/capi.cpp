@@ -1140,6 +1140,8 @@ struct DpStage {
         const uint32_t n = (uint32_t)reqs.size();
         n_strings = 0; cons_total = 0;
         if(n == 0) return LRSC_OK;
+        std::vector<uint8_t> too_long(n, 0);
+        bool any_too_long = false;
         for(DpRequest& r : reqs) {
             if(r.k == 0 || r.lq < r.k) return fail(LRSC_ERR_ARG, "dp request: kmer_len must satisfy 1 <= kmer_len <= query length");
             if(r.coverage > 1000) return fail(LRSC_ERR_UNSUPPORTED, "dp request: coverage above 1000 (12-bit column counters)");
@@ -1150,7 +1152,9 @@ struct DpStage {
             r.w_cols = dp_msa_columns(r.lq);
             r.cons_off = cons_total;
             cons_total += r.cons_cap;
-            if(((r.lq + 2 + 3) & ~3u) + 264 + r.str_cap + 16 > 64 * 1024) return fail(LRSC_ERR_UNSUPPORTED, "dp request: query longer than ~30 kb");
+            // beyond the alignment kernel's LDS staging (query + one retrieved string: about 30 kb of query): this request alone
+            // fails (its read gets LRSC_READ_DP_LIMIT), the rest of the round goes on
+            if(((r.lq + 2 + 3) & ~3u) + 264 + r.str_cap + 16 > 64 * 1024) too_long[(size_t)(&r - reqs.data())] = 1;
         }
         HIP_TRY(d_reqs.reserve(n));
         HIP_TRY(d_msa.reserve(n));
@@ -1171,12 +1175,13 @@ struct DpStage {
             uint64_t jobs = 0, sbytes = 0, obytes = 0;
             while(end < n) {
                 DpRequest& r = reqs[end];
-                r.n_str = r.cnt[0] + r.cnt[1] + r.cnt[2] + r.cnt[3];
+                r.n_str = too_long[end] ? 0u : r.cnt[0] + r.cnt[1] + r.cnt[2] + r.cnt[3];
+                any_too_long = any_too_long || too_long[end];
                 const uint64_t sb = (uint64_t)r.n_str * r.str_cap, ob = (uint64_t)r.n_str * r.ops_cap;
                 if(end > begin && sbytes + obytes + sb + ob + (jobs + r.n_str) * (sizeof(DpJob) + sizeof(DpAlignOut)) > budget) break;
                 r.job_first = jobs; r.str_off = sbytes; r.ops_off = obytes;
                 jobs += r.n_str; sbytes += sb; obytes += ob;
-                max1 = std::max(max1, r.lq); max2 = std::max(max2, r.str_cap);
+                if(!too_long[end]) { max1 = std::max(max1, r.lq); max2 = std::max(max2, r.str_cap); }
                 lds = std::max(lds, dp_msa_lds_bytes(r.w_cols, r.str_cap, r.ops_cap, r.n_str));
                 ++end;
             }
@@ -1302,10 +1307,9 @@ struct DpStage {
                 HIP_TRY(hipMemcpy(mo.data(), d_msa.p + begin, (size_t)nc * sizeof(DpMsaOut), hipMemcpyDeviceToHost));
                 list.clear();
                 for(uint32_t i : todo) {
-                    if(mo[i].error == 2) return fail(LRSC_ERR_LIMIT, "msa: consensus longer than 2 x query + 128");
-                    if(mo[i].error != 1) continue;
+                    if(mo[i].error != 1) continue;                       // 0 = done; 2 = consensus beyond its capacity: stays an error of this request
                     DpRequest& r = reqs[begin + i];
-                    if(r.w_cols > 64u * (r.lq + 128)) return fail(LRSC_ERR_LIMIT, "msa: a multiple alignment needs more than 64 x its query in columns");
+                    if(r.w_cols > 64u * (r.lq + 128)) continue;           // gives up on this pile-up: the request keeps its error
                     r.w_cols *= 2;
                     list.push_back(i);
                 }
@@ -1321,6 +1325,13 @@ struct DpStage {
             }
             n_strings += jobs;
             begin = end;
+        }
+        if(any_too_long) {
+            DpMsaOut bad{};
+            bad.error = 3;
+            for(uint32_t i = 0; i < n; ++i)
+                if(too_long[i]) HIP_TRY(hipMemcpyAsync(d_msa.p + i, &bad, sizeof(bad), hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
         }
         return LRSC_OK;
     }
@@ -1451,6 +1462,7 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
     HIP_TRY(hipStreamSynchronize(ctx->stream));
 
     std::vector<ReadWork> work(n);
+    std::vector<int> skipped(n, 0);
     uint64_t ws_total = 0, out_total = 0, piece_total = 0;
     for(uint32_t r = 0; r < n; ++r) {
         ReadWork& w = work[r];
@@ -1460,8 +1472,15 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
         w.out_off = out_total; w.piece_off = piece_total; w.ws_off = ws_total;
         if(ns < 2) continue;                                          // nothing to correct: the read is discarded
         const char* lerr = nullptr;
-        const size_t o = layout_read_work(w, rlen, ns, plan[r], p.no_dp != 0, p.split != 0, (uint32_t)p.idmer_len, psz, lbytes, &lerr);
-        if(lerr) return fail(LRSC_ERR_UNSUPPORTED, lerr);
+        int lcode = 0;
+        const size_t o = layout_read_work(w, rlen, ns, plan[r], p.no_dp != 0, p.split != 0, (uint32_t)p.idmer_len, psz, lbytes, &lerr, &lcode);
+        if(lerr) {
+            // this read alone exceeds a capacity: it is skipped (lq_max = 0 tells the kernels) and reported in its result
+            skipped[r] = lcode;
+            std::memset(&w, 0, sizeof(w));
+            w.out_off = out_total; w.piece_off = piece_total; w.ws_off = ws_total;
+            continue;
+        }
         out_total += ((uint64_t)w.out_cap + 15) & ~15ull;
         piece_total += w.piece_cap;
         ws_total += o;
@@ -1674,16 +1693,28 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
     uint64_t n_pieces = 0;
     for(uint32_t r = 0; r < n; ++r) {
         const ReadOut& o = ro[r];
-        if(o.error == LRSC_WALK_ERR_GEOMETRY) return fail(LRSC_ERR_ARG, "correct: a walk's geometry is out of range (seed shorter than the extension k-mer, overlapping seeds, or init k-mer > 59)");
-        if(o.error == LRSC_WALK_ERR_CODE) return fail(LRSC_ERR_UNSUPPORTED, "correct: FM-extension returned -4");
-        if(o.error == LRSC_WALK_ERR_DP) return fail(LRSC_ERR_LIMIT, "correct: a DP consensus came back shorter than its k-mer or with an error");
-        if(o.error == LRSC_WALK_ERR_OUTPUT) return fail(LRSC_ERR_LIMIT, "correct: a corrected read outgrew its output slot");
-        if(o.error != 0) return fail(LRSC_ERR_LIMIT, "correct: walk frontier / result capacity exceeded");
+        int status = skipped[r];
+        if(o.error == LRSC_WALK_ERR_GEOMETRY) status = LRSC_READ_GEOMETRY;
+        else if(o.error == LRSC_WALK_ERR_CODE) status = LRSC_READ_INTERNAL;
+        else if(o.error == LRSC_WALK_ERR_DP) status = LRSC_READ_DP_LIMIT;
+        else if(o.error == LRSC_WALK_ERR_OUTPUT) status = LRSC_READ_OUTPUT_LIMIT;
+        else if(o.error != 0) status = LRSC_READ_FRONTIER_LIMIT;
+        if(status != LRSC_READ_OK) {
+            // this read alone could not be corrected: it comes back as "not merged" (-> discard.fa) with its status
+            lrsc_read_result& R = res[r];
+            std::memset(&R, 0, sizeof(R));
+            R.piece_first = n_pieces;
+            R.status = status;
+            dst_off[r + 1] = dst_off[r];
+            ro[r].out_len = 0;
+            continue;
+        }
         lrsc_read_result& R = res[r];
         R.merge = (int32_t)o.merge; R.n_pieces = o.n_pieces; R.piece_first = n_pieces;
         R.total_reads_len = o.c[0]; R.corrected_len = o.c[1]; R.total_seed_num = o.c[2]; R.total_walk_num = o.c[3];
         R.high_error_num = o.c[4]; R.exceed_depth_num = o.c[5]; R.exceed_leave_num = o.c[6]; R.fm_num = o.c[7];
         R.dp_num = o.c[8]; R.seed_dis = o.c[9];
+        R.status = LRSC_READ_OK; R.pad = 0;
         dst_off[r + 1] = dst_off[r] + o.out_len;
         for(uint32_t j = 0; j < o.n_pieces; ++j) {
             if(piece_off && n_pieces < piece_cap) piece_off[n_pieces] = dst_off[r] + pieces[work[r].piece_off + j];

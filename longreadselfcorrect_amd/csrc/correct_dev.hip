@@ -54,7 +54,7 @@ __global__ __launch_bounds__(64, OCC) void correct_reads_kernel(FmIndexDev fm, C
             cyc_prep = R.cyc[0];
         } else { R.cyc[0] = 0; R.cyc[1] = 0; R.cyc[2] = 0; R.cyc[3] = 0; R.steps = 0; }
 
-        if(n_seeds >= 2 && !(resume && R.state == kReadDone)) {
+        if(n_seeds >= 2 && rw.lq_max != 0 && !(resume && R.state == kReadDone)) {      // lq_max == 0: the host skipped this read (capacity)
             uint8_t* ws = a.workspace + rw.ws_off;
             Walk<WIDE> W;
             W.sF = strand_consts<P>(fm.strand[LRSC_RBWT]);
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void correct_gather_kernel(CorrectArgs a, cons
     const uint32_t r = blockIdx.x;
     const uint8_t* src = a.out_codes + a.work[r].out_off;
     char* d = dst + dst_off[r];
-    const uint32_t n = a.out[r].out_len;
+    const uint32_t n = (uint32_t)(dst_off[r + 1] - dst_off[r]);            // 0 for a read the host gave up on (per-read status)
     for(uint32_t i = threadIdx.x; i < n; i += 256) d[i] = "ACGT"[src[i] & 3u];
 }
 

@@ -16,17 +16,20 @@ inline size_t layout_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 // rlen = read length, ns = its seed count (>= 2), plan = bounds of its walks, psz = 4 / 8 (narrow / wide positions),
 // lbytes = sizeof(Leaf<P>).
 inline size_t layout_read_work(ReadWork& w, uint64_t rlen, uint32_t ns, const ReadPlan& plan, bool no_dp, bool split, uint32_t idmer_len,
-                               size_t psz, size_t lbytes, const char** err)
+                               size_t psz, size_t lbytes, const char** err, int* code = nullptr)
 {
     *err = nullptr;
+    int code_local = 0;
+    if(!code) code = &code_local;
+    *code = 0;
     // every walk appends at most maxLength + 1 + |target| - initk characters, walks <= seeds, gaps sum to <= |read|
     // (a DP consensus can be longer than its query by the insertion columns it keeps: budget 2x the raw segment)
     const uint64_t cap = rlen + (uint64_t)((no_dp ? 1.2 : 2.0) * (double)rlen) + (uint64_t)ns * (2 * kMaxInitK + 16 + (no_dp ? 0 : 128)) + 64;
-    if(cap >= (1ull << 32)) { *err = "read too long"; return 0; }
+    if(cap >= (1ull << 32)) { *err = "read too long"; *code = 2; return 0; }
     w.out_cap = (uint32_t)cap;
     w.piece_cap = split ? ns : 1;
     w.lq_max = plan.lq_max;
-    if(w.lq_max >= 65535) { *err = "walk: query longer than 65534 bases"; return 0; }
+    if(w.lq_max >= 65535) { *err = "walk: query longer than 65534 bases"; *code = 1; return 0; }
     const double maxLength = (1.2 * ((double)plan.gap_max + 10)) + (double)(2 * (uint64_t)kMaxInitK);
     w.pathw = (uint32_t)(((uint64_t)maxLength + 4 + 15) / 16 + 1);
     // fixed-size regions first (their offsets are compile-time constants for the state-machine kernel), then the ones that
@@ -37,7 +40,7 @@ inline size_t layout_read_work(ReadWork& w, uint64_t rlen, uint32_t ns, const Re
     w.o_item9f = v.item9f; w.o_item9r = v.item9r; w.o_term = v.term; w.o_paths = v.paths; w.o_best = v.best;
     w.o_next9f = v.next9f; w.o_next9r = v.next9r; w.o_next5 = v.next5; w.o_flags5 = v.flags5; w.o_query = v.query; w.o_dpq = v.dpq;
     size_t o = v.total;
-    if(o >= (1ull << 32)) { *err = "read workspace too large"; return 0; }
+    if(o >= (1ull << 32)) { *err = "read workspace too large"; *code = 2; return 0; }
     return o;
 }
 

@@ -1269,7 +1269,7 @@ struct ReadSM {
             R.cyc[0] = 0; R.cyc[1] = 0; R.cyc[2] = 0; R.cyc[3] = 0; R.steps = 0;
         }
         steps0 = steps;
-        if(!(n_seeds >= 2) || (resume && R.state == kReadDone)) { pc = PC_FINAL; return; }
+        if(!(n_seeds >= 2) || lq_max == 0 || (resume && R.state == kReadDone)) { pc = PC_FINAL; return; }     // lq_max == 0: skipped by the host (capacity)
         if(!resume) {
             // pieceVec.push_back(seedVec[0])
             piece_start[n_pieces++] = 0;

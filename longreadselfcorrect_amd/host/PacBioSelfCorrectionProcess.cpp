@@ -82,6 +82,10 @@ std::vector<PacBioSelfCorrectionResult> PacBioSelfCorrectionProcess::process_bat
                 o.correctedStrs.emplace_back(m_out.data() + m_pieceOff[p], m_pieceOff[p + 1] - m_pieceOff[p]);
         }
     });
+    for(size_t i = 0; i < n; ++i)
+        if(m_res[i].status != LRSC_READ_OK)
+            std::cerr << "Warning: read " << items[i].read.id << " exceeds an internal capacity of the device path (status " << m_res[i].status
+                      << ", include/lrsc.h lrsc_read_status): written to discard.fa uncorrected\n";
     return results;
 }
 

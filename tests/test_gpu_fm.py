@@ -616,3 +616,35 @@ def test_whole_path_ragged_and_foreign_reads(api, gpu_index, oracle, small_ds, n
     np.testing.assert_array_equal(np.array([[getattr(r, n) for n in names] for r in results], dtype=np.int64), want.counters)
     assert want.counters[:, 10].sum() >= 5 and (want.counters[:, 10] == 0).sum() >= 5        # corrected and discarded reads both occur
     want.close(); ob.close(); orb.close()
+
+
+def test_per_read_capacity_limits_do_not_fail_the_batch(api, gpu_index, oracle, small_ds):
+    """A read whose walk query would be >= 65535 bases, and one whose DP-fallback query is beyond the alignment kernel's staging
+    (about 30 kb), come back uncorrected with a per-read status; every other read of the batch is corrected exactly as the oracle
+    does (the reference itself has no such bounds: SURVEY.md section 8b, include/lrsc.h lrsc_read_status)."""
+    from oracle.oracle_py import pack_reads
+
+    rng = np.random.default_rng(99)
+    reads = list(small_ds.reads[:12])
+    junk = lambda n: "".join("ACGT"[i] for i in rng.integers(0, 4, n))
+    far = reads[0][:1000] + junk(70000) + reads[1][-1000:]          # the only seeds are 70 kb apart: walk query too long
+    dpl = reads[2][:1000] + junk(36000) + reads[3][-1000:]          # 36 kb gap: FM-extension fails, the DP query is beyond the kernel's staging
+    batch = reads[:6] + [far] + reads[6:9] + [dpl] + reads[9:]
+    bases, off = pack_reads(batch)
+    p = api.params_default(5, 90)
+    ctx = gpu_index.ctx(p, 0)
+    results, pieces = ctx.correct_reads(bases, off)
+    ctx.close()
+    assert results[6].status == 1 and results[6].merge == 0 and pieces[6] == []
+    assert results[10].status == 5 and results[10].merge == 0 and pieces[10] == []
+    ok = [i for i in range(len(batch)) if i not in (6, 10)]
+    assert all(results[i].status == 0 for i in ok)
+    ob, orb = oracle.bwt_load(small_ds.prefix + ".bwt"), oracle.bwt_load(small_ds.prefix + ".rbwt")
+    b2, o2 = pack_reads([batch[i] for i in ok])
+    want = oracle.correct_reads(ob, orb, p, b2, o2)
+    names = ("total_reads_len", "corrected_len", "total_seed_num", "total_walk_num", "high_error_num", "exceed_depth_num",
+             "exceed_leave_num", "fm_num", "dp_num", "seed_dis", "merge")
+    got = np.array([[getattr(results[i], f) for f in names] for i in ok], dtype=np.int64)
+    np.testing.assert_array_equal(got, want.counters)
+    assert [pieces[i][0] for i in ok if results[i].merge] == want.correct_fa.split("\n")[1::2]
+    want.close(); ob.close(); orb.close()
