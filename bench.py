@@ -72,12 +72,12 @@ def main():
     ap.add_argument("--reads", type=int, default=100_000, help="reads per GPU (= index reads on rank 0)")
     ap.add_argument("--read-len", type=int, default=10_000)
     ap.add_argument("--reads-per-step", type=int, default=0,
-                    help="reads of one step's resident sub-batch (0 = stage default: all reads for `seeds`; 28000 otherwise, so that the driver's ""--steps 20 --warmup 5 fits its 600 s: a correct step is latency-bound, see DESIGN.md section 4)")
+                    help="reads of one step's resident sub-batch (0 = stage default: all reads for `seeds`; 20000 otherwise, so that the driver's ""--steps 20 --warmup 5 fits its 600 s: a correct step is latency-bound, see DESIGN.md section 4)")
     ap.add_argument("--streams", type=int, default=0,
                     help="correct stages: a step's sub-batch is cut into this many parts, corrected concurrently by one host thread + "
                          "ctx (HIP stream) each, so that the DP rounds of one part overlap the extension of the others "
                          "(default 1: on one GPU the parts contend for the same wavefront slots and the step gets slower)")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 disables it and parity_sample)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 disables it and parity_sample)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="oracle threads of the cpu_baseline leg (0 = all host cores of this process)")
     ap.add_argument("--stage", choices=list(STAGE_INFO), default="correct",
                     help="correct (default): BASELINE configs[2], the whole per-read path with the DP fallback; correct-nodp: the "
@@ -141,7 +141,7 @@ def main():
     else:
         bases, off = api.synth_reads(0x5EED0002, genome, n_reads, args.read_len,
                                      first_read=lrdist.weak_shard_first_read(rank, n_reads))
-    per_step = args.reads_per_step or (n_reads if args.stage == "seeds" else 28_000)
+    per_step = args.reads_per_step or (n_reads if args.stage == "seeds" else 20_000)
     per_step = max(1, min(per_step, n_reads))
     n_streams = 1 if args.stage == "seeds" else max(1, args.streams or 1)
     cuts = list(range(0, n_reads, per_step)) + [n_reads]
@@ -194,7 +194,9 @@ def main():
         return group_bases[g]
 
     for i in range(args.warmup):
+        t_w = time.perf_counter()
         step(i, False)
+        log(f"warmup step {i + 1}/{args.warmup}: {time.perf_counter() - t_w:.1f}s")
     for c in ctxs:
         c.stats_reset()
 
@@ -210,6 +212,8 @@ def main():
     my_bases = 0
     for i in range(args.steps):
         my_bases += step(args.warmup + i, True)
+        if rank == 0:
+            log(f"step {i + 1}/{args.steps} done, {time.perf_counter() - t0:.1f}s into the timed region")   # progress line (watchdogs)
     fence()
     elapsed = time.perf_counter() - t0
 
