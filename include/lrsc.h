@@ -182,6 +182,9 @@ typedef struct lrsc_seed {
 } lrsc_seed;
 /* KmerThreshold table (PacBio/KmerThreshold.cpp:43-79) for `coverage`: out[mode*52 + k], mode 0..2, k 0..51. */
 int lrsc_kmer_thresholds(int coverage, float* out);
+/* The same table for k up to `end` (KmerThreshold::initialize(s, end, coverage, ""), e.g. `stride kmerfreq`: end = 100):
+ * out[mode*(end+2) + k], k 0..end+1. */
+int lrsc_kmer_thresholds_range(int coverage, int end, float* out);
 /* Seeds of every read of a resident batch: k-mer grid, LongReadProbe::getSeqAttribute,
  * searchSeedsWithHybridKmers (PacBio/LongReadProbe.cpp:34-227), all on the device. */
 int lrsc_batch_find_seeds(lrsc_ctx* ctx, lrsc_batch* b);
@@ -193,6 +196,26 @@ int lrsc_batch_seeds(lrsc_ctx* ctx, lrsc_batch* b, uint32_t* seed_count, lrsc_se
 /* Convenience: upload, find, fetch, release. */
 int lrsc_find_seeds(lrsc_ctx* ctx, const char* reads, const uint64_t* read_off, uint32_t n_reads,
                     uint32_t* seed_count, lrsc_seed* seeds, uint64_t cap, uint64_t* n_seeds, int8_t* attribute);
+
+/* ---- diagnostics of --debugseed / --onlyseed ---------------------------------------------------------------- */
+/* What the reference writes per read under <out>/seed and <out>/extend when DebugSeed is set
+ * (LongReadProbe.cpp:109-113,123-175,220-225; PacBioSelfCorrectionProcess.cpp:71-75,130-140).  Collection is off by
+ * default and costs nothing then; switch it on for a batch BEFORE lrsc_batch_find_seeds. */
+enum {
+    LRSC_DEBUG_OUTCASTS = 1,   /* seeds dropped by removeHitchhikingSeeds        -> seed/error/<read>.seed */
+    LRSC_DEBUG_WALKS    = 2,   /* FM walks that failed, DP fallbacks that failed -> extend/<read>.ext, .dp */
+    LRSC_DEBUG_RATIO    = 4    /* getSeqAttribute's repeat ratio per position    -> extend/<read>.log      */
+};
+int lrsc_batch_set_debug(lrsc_batch* b, int flags);
+/* Dropped seeds, laid out like lrsc_batch_seeds (initial-seed order within a read). */
+int lrsc_batch_outcast_seeds(lrsc_ctx* ctx, lrsc_batch* b, uint32_t* outcast_count, lrsc_seed* seeds, uint64_t cap,
+                             uint64_t* n_seeds);
+/* ratio[total_bases]: the value getSeqAttribute compares with 0.02 (undefined for reads shorter than start_kmer_len). */
+int lrsc_batch_repeat_ratio(lrsc_ctx* ctx, lrsc_batch* b, float* ratio);
+/* After lrsc_batch_correct: one byte per seed in lrsc_batch_seeds order.  For seed i >= 1 of a read, 0 = the walk that
+ * targets it succeeded by FM-extension (or it was skipped as a next-target); otherwise bits 0-3 = firstFMExtensionType + 4
+ * (3 high error, 2 exceed depth, 1 exceed leaves) and bit 4 = the DP/MSA fallback failed too.  The walk's source is seed i-1. */
+int lrsc_batch_walk_log(lrsc_ctx* ctx, lrsc_batch* b, uint8_t* log, uint64_t cap);
 
 /* ---- seed-to-seed FM-extend ----------------------------------------------------------------------- */
 /* One LongReadSelfCorrectByOverlap(sourceSeed, strBetweenSrcTarget, targetSeed, disBetweenSrcTarget,

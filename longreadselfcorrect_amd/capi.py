@@ -190,6 +190,11 @@ class Lrsc:
         L.lrsc_batch_kmer_grid.argtypes = [C.c_void_p, C.c_void_p]
         L.lrsc_kmer_thresholds.argtypes = [C.c_int, C.c_void_p]
         L.lrsc_batch_find_seeds.argtypes = [C.c_void_p, C.c_void_p]
+        L.lrsc_kmer_thresholds_range.argtypes = [C.c_int, C.c_int, C.c_void_p]
+        L.lrsc_batch_set_debug.argtypes = [C.c_void_p, C.c_int]
+        L.lrsc_batch_outcast_seeds.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.lrsc_batch_repeat_ratio.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.lrsc_batch_walk_log.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
         L.lrsc_batch_seeds.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
                                        C.c_void_p]
         L.lrsc_find_seeds.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64,
@@ -227,6 +232,11 @@ class Lrsc:
     def kmer_thresholds(self, coverage: int) -> np.ndarray:
         out = np.zeros((3, 52), dtype=np.float32)
         self.check(self.lib.lrsc_kmer_thresholds(coverage, _ptr(out)), "lrsc_kmer_thresholds")
+        return out
+
+    def kmer_thresholds_range(self, coverage: int, end: int) -> np.ndarray:
+        out = np.zeros((3, end + 2), dtype=np.float32)
+        self.check(self.lib.lrsc_kmer_thresholds_range(coverage, end, _ptr(out)), "lrsc_kmer_thresholds_range")
         return out
 
     # ---- synthetic data -------------------------------------------------------------------
@@ -518,6 +528,33 @@ class Batch:
                 continue
             api.check(st, "lrsc_batch_seeds")
             return count, seeds[: n.value].copy(), attr
+
+    # --debugseed / --onlyseed diagnostics (include/lrsc.h: LRSC_DEBUG_*)
+    DEBUG_OUTCASTS, DEBUG_WALKS, DEBUG_RATIO = 1, 2, 4
+
+    def set_debug(self, flags: int):
+        self.ctx.api.check(self.ctx.api.lib.lrsc_batch_set_debug(self.h, flags), "lrsc_batch_set_debug")
+
+    def outcast_seeds(self):
+        """-> (outcast_count uint32[n_reads], seeds SEED_DTYPE[n]): what removeHitchhikingSeeds dropped."""
+        api = self.ctx.api
+        count = np.zeros(self.n_reads, dtype=np.uint32)
+        n = C.c_uint64()
+        api.check(api.lib.lrsc_batch_outcast_seeds(self.ctx.h, self.h, _ptr(count), None, 2 ** 62, C.byref(n)), "lrsc_batch_outcast_seeds")
+        seeds = np.zeros(max(1, n.value), dtype=SEED_DTYPE)
+        api.check(api.lib.lrsc_batch_outcast_seeds(self.ctx.h, self.h, _ptr(count), _ptr(seeds), seeds.size, C.byref(n)),
+                  "lrsc_batch_outcast_seeds")
+        return count, seeds[: n.value].copy()
+
+    def repeat_ratio(self) -> np.ndarray:
+        out = np.zeros(self.total_bases, dtype=np.float32)
+        self.ctx.api.check(self.ctx.api.lib.lrsc_batch_repeat_ratio(self.ctx.h, self.h, _ptr(out)), "lrsc_batch_repeat_ratio")
+        return out
+
+    def walk_log(self, n_seeds: int) -> np.ndarray:
+        out = np.zeros(max(1, n_seeds), dtype=np.uint8)
+        self.ctx.api.check(self.ctx.api.lib.lrsc_batch_walk_log(self.ctx.h, self.h, _ptr(out), out.size), "lrsc_batch_walk_log")
+        return out[:n_seeds]
 
     def correct(self):
         """lrsc_batch_correct on the resident batch -> (results ReadResult[n], piece offsets uint64[], corrected bytes uint8[])."""

@@ -133,6 +133,13 @@ struct lrsc_batch {
     void* d_scan_tmp = nullptr;
     size_t scan_tmp_cap = 0;
     bool seeds_done = false;
+    // --debugseed collection (lrsc_batch_set_debug)
+    int debug_flags = 0;
+    int32_t* d_outcasts = nullptr;
+    uint32_t* d_outcast_count = nullptr;
+    uint8_t* d_walk_log = nullptr;
+    float* d_ratio = nullptr;
+    bool walk_log_done = false;
 };
 
 // ---------------------------------------------------------------------------------------
@@ -692,7 +699,7 @@ extern "C" void lrsc_batch_destroy(lrsc_batch* b)
     if(b->d_off) (void)hipFree(b->d_off);
     if(b->d_chunk) (void)hipFree(b->d_chunk);
     void* ptrs[] = {b->d_freq, b->d_base_counted, b->d_valid, b->d_flags, b->d_zeros, b->d_attr, b->d_start_bits, b->d_seeds,
-                    b->d_seed_count, b->d_thr, b->d_scan_tmp};
+                    b->d_seed_count, b->d_thr, b->d_scan_tmp, b->d_outcasts, b->d_outcast_count, b->d_walk_log, b->d_ratio};
     for(void* q : ptrs) if(q) (void)hipFree(q);
     delete b;
 }
@@ -751,12 +758,14 @@ static const float kThresholdFormula[3][6] = {
     {0.0003348214286, -0.009112394958, 0.04286714686, 0.240519958, -1.8793367350, 21.29319228},
     {0.01714285714, -0.6193907563, 2.266956783, 17.28450630, -100.6983493, 1103.571729}};
 
-extern "C" int lrsc_kmer_thresholds(int coverage, float* out)
+// KmerThreshold::initialize(s, e, cov, dir) (PacBio/KmerThreshold.cpp:43-63): table[mode][0 .. end+1], zero below max(s, 15) and at
+// end + 1, the running minimum ("cavity") of max(formula, 2) in between.
+extern "C" int lrsc_kmer_thresholds_range(int coverage, int end, float* out)
 {
-    if(!out) return fail(LRSC_ERR_ARG, "null");
-    const int start = 15, end = 50;
+    if(!out || end < 15) return fail(LRSC_ERR_ARG, "null table / end < 15");
+    const int start = 15, stride = end + 2;
     for(int mode = 0; mode < 3; ++mode) {
-        for(int k = 0; k < 52; ++k) out[mode * 52 + k] = 0.0f;
+        for(int k = 0; k < stride; ++k) out[mode * stride + k] = 0.0f;
         float cavity = std::numeric_limits<float>::max();
         const float* f = kThresholdFormula[mode];
         const int x = coverage;
@@ -764,10 +773,15 @@ extern "C" int lrsc_kmer_thresholds(int coverage, float* out)
             float v = f[0] * x * x + f[1] * x * y + f[2] * y * y + f[3] * x + f[4] * y + f[5];
             v = std::fmax(v, 2.0f);
             cavity = std::fmin(cavity, v);
-            out[mode * 52 + y] = cavity;
+            out[mode * stride + y] = cavity;
         }
     }
     return LRSC_OK;
+}
+
+extern "C" int lrsc_kmer_thresholds(int coverage, float* out)
+{
+    return lrsc_kmer_thresholds_range(coverage, 50, out);         // pbcorrect: initialize(startKmerLen, kmerLenUpBound = 50, ...)
 }
 
 static int batch_setup_rows(lrsc_ctx* ctx, lrsc_batch* b)
@@ -836,6 +850,11 @@ static int batch_setup_seeds(lrsc_ctx* ctx, lrsc_batch* b)
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_start_bits), ((b->total_bases + 255) / 256) * 4 * sizeof(unsigned long long)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_seeds), b->seed_cap * kSeedInts * sizeof(int32_t)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_seed_count), (size_t)b->n_reads * sizeof(uint32_t)));
+    if(b->debug_flags & LRSC_DEBUG_RATIO) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_ratio), b->total_bases * sizeof(float)));
+    if(b->debug_flags & LRSC_DEBUG_OUTCASTS) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_outcasts), b->seed_cap * kSeedInts * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_outcast_count), (size_t)b->n_reads * sizeof(uint32_t)));
+    }
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_thr), 3 * 52 * sizeof(float)));
     float thr[3 * 52];
     (void)lrsc_kmer_thresholds(ctx->params.pb_coverage, thr);
@@ -858,6 +877,7 @@ static SeedArgs batch_seed_args(const lrsc_ctx* ctx, const lrsc_batch* b)
     a.hh_ratio = p.hh_ratio;
     a.thresholds = b->d_thr;
     a.flags = b->d_flags; a.zeros = b->d_zeros; a.attribute = b->d_attr; a.start_bits = b->d_start_bits; a.seeds = b->d_seeds; a.seed_count = b->d_seed_count;
+    a.outcasts = b->d_outcasts; a.outcast_count = b->d_outcast_count; a.ratio = b->d_ratio;
     return a;
 }
 
@@ -922,6 +942,68 @@ extern "C" int lrsc_find_seeds(lrsc_ctx* ctx, const char* reads, const uint64_t*
     if(st == LRSC_OK) st = lrsc_batch_seeds(ctx, b, seed_count, seeds, cap, n_seeds, attribute);
     lrsc_batch_destroy(b);
     return st;
+}
+
+// ---- --debugseed / --onlyseed diagnostics ------------------------------------------------------------------
+extern "C" int lrsc_batch_set_debug(lrsc_batch* b, int flags)
+{
+    if(!b) return fail(LRSC_ERR_ARG, "null batch");
+    if(flags & ~(LRSC_DEBUG_OUTCASTS | LRSC_DEBUG_WALKS | LRSC_DEBUG_RATIO)) return fail(LRSC_ERR_ARG, "unknown debug flag");
+    if(b->d_seeds) return fail(LRSC_ERR_ARG, "lrsc_batch_set_debug must precede lrsc_batch_find_seeds");
+    b->debug_flags = flags;
+    return LRSC_OK;
+}
+
+extern "C" int lrsc_batch_outcast_seeds(lrsc_ctx* ctx, lrsc_batch* b, uint32_t* outcast_count, lrsc_seed* seeds, uint64_t cap,
+                                        uint64_t* n_seeds)
+{
+    if(!ctx || !b || b->ctx != ctx || !outcast_count || !n_seeds) return fail(LRSC_ERR_ARG, "null / foreign batch");
+    if(!b->seeds_done || !b->d_outcasts) return fail(LRSC_ERR_ARG, "needs LRSC_DEBUG_OUTCASTS and lrsc_batch_find_seeds");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpy(outcast_count, b->d_outcast_count, (size_t)b->n_reads * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    std::vector<uint64_t> off(b->n_reads + 1);
+    HIP_TRY(hipMemcpy(off.data(), b->d_off, off.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    uint64_t total = 0;
+    for(uint32_t r = 0; r < b->n_reads; ++r) total += outcast_count[r];
+    *n_seeds = total;
+    if(total > cap) return fail(LRSC_ERR_CAPACITY, "seed buffer too small");
+    uint64_t w = 0;
+    for(uint32_t r = 0; seeds && r < b->n_reads; ++r) {
+        if(outcast_count[r] == 0) continue;
+        const uint64_t slab = seed_slab(off[r], r, b->min_k);
+        HIP_TRY(hipMemcpy(seeds + w, b->d_outcasts + slab * kSeedInts, (size_t)outcast_count[r] * sizeof(lrsc_seed), hipMemcpyDeviceToHost));
+        w += outcast_count[r];
+    }
+    return LRSC_OK;
+}
+
+extern "C" int lrsc_batch_repeat_ratio(lrsc_ctx* ctx, lrsc_batch* b, float* ratio)
+{
+    if(!ctx || !b || b->ctx != ctx || !ratio) return fail(LRSC_ERR_ARG, "null / foreign batch");
+    if(!b->seeds_done || !b->d_ratio) return fail(LRSC_ERR_ARG, "needs LRSC_DEBUG_RATIO and lrsc_batch_find_seeds");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpy(ratio, b->d_ratio, b->total_bases * sizeof(float), hipMemcpyDeviceToHost));
+    return LRSC_OK;
+}
+
+extern "C" int lrsc_batch_walk_log(lrsc_ctx* ctx, lrsc_batch* b, uint8_t* log, uint64_t cap)
+{
+    if(!ctx || !b || b->ctx != ctx || !log) return fail(LRSC_ERR_ARG, "null / foreign batch");
+    if(!b->walk_log_done || !b->d_walk_log) return fail(LRSC_ERR_ARG, "needs LRSC_DEBUG_WALKS and lrsc_batch_correct");
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<uint32_t> count(b->n_reads);
+    std::vector<uint64_t> off(b->n_reads + 1);
+    HIP_TRY(hipMemcpy(count.data(), b->d_seed_count, count.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(off.data(), b->d_off, off.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    std::vector<uint8_t> all(b->seed_cap);
+    HIP_TRY(hipMemcpy(all.data(), b->d_walk_log, b->seed_cap, hipMemcpyDeviceToHost));
+    uint64_t w = 0;
+    for(uint32_t r = 0; r < b->n_reads; ++r) {
+        if(w + count[r] > cap) return fail(LRSC_ERR_CAPACITY, "walk log buffer too small");
+        if(count[r]) std::memcpy(log + w, all.data() + seed_slab(off[r], r, b->min_k), count[r]);
+        w += count[r];
+    }
+    return LRSC_OK;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1416,6 +1498,12 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
     CorrectArgs a{};
     a.codes = b->d_codes; a.read_off = b->d_off; a.seeds = b->d_seeds; a.seed_count = b->d_seed_count;
     a.n_reads = n; a.min_k = b->min_k;
+    if(b->debug_flags & LRSC_DEBUG_WALKS) {
+        if(!b->d_walk_log) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_walk_log), b->seed_cap));
+        HIP_TRY(hipMemsetAsync(b->d_walk_log, 0, b->seed_cap, ctx->stream));
+        a.walk_log = b->d_walk_log;
+        b->walk_log_done = false;
+    }
     a.plan = d_plan.p; a.out = d_out.p; a.work = d_work.p; a.order = d_order.p;
     a.seed_size = (uint32_t)p.idmer_len; a.min_overlap = (uint32_t)p.min_kmer_len; a.max_leaves = (uint32_t)p.max_leaves;
     a.start_kmer_len = p.start_kmer_len; a.next_target = p.next_target; a.split = p.split; a.no_dp = p.no_dp;
@@ -1680,6 +1768,7 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
         }
     }
     a.n_reads = n;
+    if(a.walk_log) b->walk_log_done = true;
     std::vector<uint32_t> pieces(std::max<uint64_t>(piece_total, 1));
     if(piece_total) HIP_TRY(hipMemcpy(pieces.data(), d_pieces.p, (size_t)piece_total * sizeof(uint32_t), hipMemcpyDeviceToHost));
     if(std::getenv("LRSC_CORRECT_PROFILE")) {

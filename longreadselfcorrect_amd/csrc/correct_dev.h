@@ -80,6 +80,9 @@ struct CorrectArgs {
     double pacbio_error_rate;
     const double* freqs_of_kmer_size;
     DevCounters* ctr;
+    // --debugseed: one byte per seed (same slab indexing as `seeds`), written for the target seed of every walk the FM-extension
+    // gave up on: (first FM result code + 4) | 0x10 if the DP fallback failed too (the lines of extend/<read>.ext and .dp)
+    uint8_t* walk_log;
     // debugging aid (LRSC_SM_TRACE): the state-machine kernel records (pc, request, answer) of read `trace_read` per sweep
     uint32_t dbg_flags;              // LRSC_SM_DBG: timing ablations (work done twice; results unchanged)
     unsigned long long* prof;        // LRSC_SM_PROFILE: 16 tick / count totals per wavefront (state-machine kernel)

@@ -39,6 +39,7 @@ __global__ __launch_bounds__(64, OCC) void correct_reads_kernel(FmIndexDev fm, C
         const uint32_t n_seeds = a.seed_count[r];
         const int32_t* seeds = a.seeds + seed_slab(rs, r, a.min_k) * kSeedInts;
         uint8_t* out = a.out_codes + rw.out_off;
+        uint8_t* wl = a.walk_log ? a.walk_log + seed_slab(rs, r, a.min_k) : nullptr;
         uint32_t* piece_start = a.piece_start + rw.piece_off;
 
         const bool resume = a.resume != 0;                                       // the read was parked waiting for its DP result
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(64, OCC) void correct_reads_kernel(FmIndexDev fm, C
                         }
                     }
                 } else if(a.split) {
+                    if(wl) wl[it] |= 0x10;
                     if(out_len + (uint32_t)T0[1] > rw.out_cap) error = LRSC_WALK_ERR_OUTPUT;
                     else {
                         piece_start[n_pieces++] = out_len;
@@ -136,6 +138,7 @@ __global__ __launch_bounds__(64, OCC) void correct_reads_kernel(FmIndexDev fm, C
                         correctedLen += T0[1];
                     }
                 } else {
+                    if(wl) wl[it] |= 0x10;
                     const int raw = (T0[0] + T0[1] - 1) - S_end;
                     if(out_len + (uint32_t)raw > rw.out_cap) error = LRSC_WALK_ERR_OUTPUT;
                     else {
@@ -266,6 +269,7 @@ __global__ __launch_bounds__(64, OCC) void correct_reads_kernel(FmIndexDev fm, C
                 }
                 if(error) break;
                 totalWalkNum++;
+                if(wl) wl[it] = (uint8_t)((firstType + 4) | (a.no_dp ? 0x10 : 0));
                 const int32_t* T0 = seeds + (uint64_t)it * kSeedInts;               // target = *iterTarget
                 if(!a.no_dp) {
                     // correctByMSAlignment (:208-236): park the read with its query = src k-mer + raw segment + target seed

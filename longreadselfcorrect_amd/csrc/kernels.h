@@ -65,9 +65,13 @@ struct SeedArgs {
     unsigned long long* flags;    // [pos] (repeat) | (garbage << 32), later its inclusive scan
     uint32_t* zeros;              // [pos] zero-frequency non-low-complexity scan k-mers, later its inclusive scan
     uint8_t* attribute;           // [pos] 1 unique / 2 repeat (LongReadProbe::getSeqAttribute)
+    float* ratio;                 // [pos] the repeat ratio behind `attribute` (extend/<read>.log of --debugseed), or nullptr
     unsigned long long* start_bits;   // bit pos: the static k-mer at pos passes the scan's first-iteration tests (a seed can start here)
     int32_t* seeds;               // kSeedInts per seed, read r's slab starts at seed_slab(r)
     uint32_t* seed_count;         // [read]
+    // --debugseed (both null otherwise): the seeds removeHitchhikingSeeds drops, same slab layout as `seeds`
+    int32_t* outcasts;
+    uint32_t* outcast_count;      // [read]
 };
 // first seed record of read r: reads can hold at most len/15 + 1 seeds (static k-mers are >= 15 long... any k >= 1: len + 1)
 __host__ __device__ inline uint64_t seed_slab(uint64_t read_start, uint32_t r, uint32_t min_k) { return read_start / min_k + r; }

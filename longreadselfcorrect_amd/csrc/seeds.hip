@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void seed_attribute_kernel(SeedArgs a)
         while(a.read_off[r + 1] <= gid) ++r;
         const int64_t s = (int64_t)a.read_off[r], e = (int64_t)a.read_off[r + 1];
         uint8_t attr = 1;
-        if(a.manual) {
+        if(a.manual && !a.ratio) {
             attr = (uint8_t)a.mode;
         } else if(e - s >= a.start_kmer_len) {
             const int range = 300;
@@ -97,6 +97,8 @@ __global__ __launch_bounds__(256) void seed_attribute_kernel(SeedArgs a)
             const int size = (int)(right - left + 1) - boxneg;
             const float ratio = (float)((double)((float)box2 / (float)size) + 0.0005);
             if((double)ratio >= 0.02) attr = 2;
+            if(a.ratio) a.ratio[gid] = ratio;
+            if(a.manual) attr = (uint8_t)a.mode;          // the reference computes the attribute, then overwrites it (:39-40)
         }
         a.attribute[gid] = attr;
         // Can the greedy scan start a seed here?  Its first inner iteration (currPos == initPos, dynamicKmer == staticKmer,
@@ -335,17 +337,22 @@ __global__ __launch_bounds__(64) void seed_scan_kernel(FmIndexDev fm, SeedArgs a
                         if((subject[3] & 1) && freqDiff > inv_hh) query[3] |= 2;   // LOW  --> HIGH
                     }
                 }
-                uint32_t w = 0;
+                uint32_t w = 0, n_out = 0;
+                int32_t* oc = a.outcasts ? a.outcasts + (out - a.seeds) : nullptr;     // the read's slab of the outcast array
                 for(uint32_t q = 0; q < n_seeds; ++q) {
                     int32_t* src = out + (uint64_t)q * kSeedInts;
-                    if(src[3] & 2) continue;
+                    if(src[3] & 2) {
+                        if(oc) { for(uint32_t i = 0; i < kSeedInts; ++i) oc[(uint64_t)n_out * kSeedInts + i] = i == 3 ? (src[i] & 1) : src[i]; ++n_out; }
+                        continue;
+                    }
                     int32_t* dst = out + (uint64_t)w * kSeedInts;
                     if(w != q) for(uint32_t i = 0; i < kSeedInts; ++i) dst[i] = src[i];
                     ++w;
                 }
                 n_seeds = w;
-            }
-        }
+                if(a.outcast_count) a.outcast_count[r] = n_out;
+            } else if(a.outcast_count) a.outcast_count[r] = 0;
+        } else if(a.outcast_count) a.outcast_count[r] = 0;
         a.seed_count[r] = n_seeds;
     }
     flush_counters(ctr, n_rank, n_blk);

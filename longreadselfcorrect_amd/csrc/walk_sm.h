@@ -305,6 +305,7 @@ struct ReadSM {
     LRSC_SM uint8_t* out() const { return sm_global(LRSC_A.out_codes) + sm_global(LRSC_A.work)[r].out_off; }
     LRSC_SM uint32_t* piece_start() const { return sm_global(LRSC_A.piece_start) + sm_global(LRSC_A.work)[r].piece_off; }
     LRSC_SM uint32_t out_cap() const { return sm_global(LRSC_A.work)[r].out_cap; }
+    LRSC_SM uint8_t* walk_log() const { return LRSC_A.walk_log ? LRSC_A.walk_log + seed_slab(rs, r, LRSC_A.min_k) : nullptr; }
     LRSC_SM int64_t& ctr(int j) const { return sm_global(LRSC_A.out)[r].c[j]; }
     LRSC_SM const StrandC<P>& sF() const { return LRSC_SF; }
     LRSC_SM const StrandC<P>& sR() const { return LRSC_SR; }
@@ -1302,6 +1303,7 @@ struct ReadSM {
                         }
                     }
                 } else if(LRSC_A.split) {
+                    if(uint8_t* wl = walk_log()) wl[it] |= 0x10;
                     if(out_len + (uint32_t)T0[1] > out_cap()) error = LRSC_WALK_ERR_OUTPUT;
                     else {
                         piece_start[n_pieces++] = out_len;
@@ -1310,6 +1312,7 @@ struct ReadSM {
                         ctr(1) += T0[1];
                     }
                 } else {
+                    if(uint8_t* wl = walk_log()) wl[it] |= 0x10;
                     const int raw = (T0[0] + T0[1] - 1) - S_end;
                     if(out_len + (uint32_t)raw > out_cap()) error = LRSC_WALK_ERR_OUTPUT;
                     else {
@@ -1440,6 +1443,7 @@ struct ReadSM {
         }
         if(error) { pc = PC_FINAL; return; }
         ctr(3)++;
+        if(uint8_t* wl = walk_log()) wl[it] = (uint8_t)((firstType + 4) | (LRSC_A.no_dp ? 0x10 : 0));
         const int32_t* T0 = seeds + (uint64_t)it * kSeedInts;               // target = *iterTarget
         if(!LRSC_A.no_dp) {
             // correctByMSAlignment (:208-236): park the read with its query = src k-mer + raw segment + target seed

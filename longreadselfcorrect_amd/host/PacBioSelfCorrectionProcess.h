@@ -2,6 +2,7 @@
 // (PacBio/PacBioSelfCorrectionProcess.h:24-127) over the C ABI (include/lrsc.h).
 #pragma once
 #include <cstdint>
+#include <cstdio>
 #include <fstream>
 #include <string>
 #include <vector>
@@ -29,6 +30,7 @@ struct PacBioSelfCorrectionResult {
     int64_t totalReadsLen = 0, correctedLen = 0, totalSeedNum = 0, totalWalkNum = 0, highErrorNum = 0, exceedDepthNum = 0,
             exceedLeaveNum = 0, FMNum = 0, DPNum = 0, seedDis = 0;
     double Timer_Seed = 0, Timer_FM = 0, Timer_DP = 0;
+    std::vector<lrsc_seed> seeds;   // --onlyseed: the read's seeds (the reference parks them in SeedFeature::Log(), .cpp:58-62)
 };
 
 // Batched processor: one instance per device (the framework runs one worker thread per instance and deals whole
@@ -41,6 +43,9 @@ public:
     std::vector<PacBioSelfCorrectionResult> process_batch(const std::vector<SequenceWorkItem>& items);
     PacBioSelfCorrectionResult process(const SequenceWorkItem& item);     // classic concept (one-item batch)
 private:
+    // --debugseed / --onlyseed: the per-read files of LongReadProbe.cpp:109-113,123-175,220-225 and .cpp:71-75,130-140
+    void runWithDiagnostics(const std::vector<SequenceWorkItem>& items, std::vector<PacBioSelfCorrectionResult>& results,
+                            uint64_t& nPieces, uint64_t& used);
     const PacBioSelfCorrectionParameters m_params;
     lrsc_ctx* m_ctx = nullptr;
     // staging buffers, kept between batches
@@ -49,7 +54,8 @@ private:
     std::vector<lrsc_read_result> m_res;
 };
 
-// PacBioSelfCorrectionPostProcess (reference .cpp:250-380): correct.fa / discard.fa + the stats block
+// PacBioSelfCorrectionPostProcess (reference .cpp:250-380): correct.fa / discard.fa + the stats block;
+// --onlyseed: total.seed (one line per read with a wrong seed) + the TOTAL line on stdout
 class PacBioSelfCorrectionPostProcess {
 public:
     explicit PacBioSelfCorrectionPostProcess(const PacBioSelfCorrectionParameters& params);
@@ -62,6 +68,9 @@ private:
     int64_t m_totalReadsLen = 0, m_correctedLen = 0, m_totalSeedNum = 0, m_totalWalkNum = 0, m_highErrorNum = 0,
             m_exceedDepthNum = 0, m_exceedLeaveNum = 0, m_FMNum = 0, m_DPNum = 0, m_OutcastNum = 0, m_seedDis = 0;
     double m_Timer_Seed = 0, m_Timer_FM = 0, m_Timer_DP = 0;
+    static void summarize(FILE* out, const size_t* status, const std::string& subject);       // reference :372-380
+    FILE* m_pStatusWriter = nullptr;
+    size_t m_status[3] = {0, 0, 0};            // seeds that are correct / wrong / outside every barcode block
 };
 
 } // namespace stride

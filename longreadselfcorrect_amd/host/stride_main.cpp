@@ -2,7 +2,6 @@
 // MI355X back end.  Option surface, defaults, validation messages and exit codes follow the reference's
 // StriDe/PacBioSelfCorrection.cpp:32-140,262-434 and StriDe/StriDe.cpp:62-126; extra flags: --devices, --batch.
 #include <getopt.h>
-#include <sys/stat.h>
 
 #include <array>
 #include <cstdlib>
@@ -15,6 +14,7 @@
 #include <vector>
 
 #include "../../include/lrsc.h"
+#include "BCode.h"
 #include "PacBioSelfCorrectionProcess.h"
 #include "SequenceProcessFramework.h"
 
@@ -26,6 +26,10 @@
 #define RBWT_EXT ".rbwt"
 
 using namespace stride;
+namespace stride {
+int kmerfreqMain(int argc, char** argv);       // tools.cpp
+int kmercheckMain(int argc, char** argv);
+}
 
 static const char* CORRECT_VERSION_MESSAGE = SUBPROGRAM " Version " PACKAGE_VERSION " (MI355X back end)\n";
 
@@ -143,13 +147,14 @@ static void parsePacBioSelfCorrectionOptions(int argc, char** argv)
     if(opt::directory.empty()) { std::cerr << SUBPROGRAM << ": no directory\n"; die = true; }
     else {
         opt::directory += "/";
-        if(mkdir(opt::directory.c_str(), 0777) != 0 && errno != EEXIST) {
-            // the reference shells out to `mkdir -p` (:346-363); one level is created here, nested paths via system()
-            if(system(("mkdir -p " + opt::directory).c_str()) != 0) {
+        // reference :346-363: with --debugseed the per-read files go to extend/ and seed/ (+ seed/error/)
+        std::vector<std::string> subdir(1, std::string(""));
+        if(opt::DebugSeed) { subdir.clear(); subdir.push_back("extend/"); subdir.push_back("seed/error/"); }
+        for(const std::string& sub : subdir)
+            if(system(("mkdir -p " + opt::directory + sub).c_str()) != 0) {
                 std::cerr << SUBPROGRAM << ": something wrong making directory: " << opt::directory << "\n";
                 die = true;
             }
-        }
     }
     if(opt::PBcoverage <= 0) { std::cerr << SUBPROGRAM ": invalid number of coverage: " << opt::PBcoverage << ", must be greater than zero\n"; die = true; }
     if(opt::ErrorRate < 0 || opt::ErrorRate > 1) { std::cerr << SUBPROGRAM ":invalid error rate: " << opt::ErrorRate << ", must be 0 ~ 1\n"; die = true; }
@@ -169,10 +174,8 @@ static void parsePacBioSelfCorrectionOptions(int argc, char** argv)
 static int PacBioSelfCorrectionMain(int argc, char** argv)
 {
     parsePacBioSelfCorrectionOptions(argc, argv);
-    if(opt::OnlySeed || opt::DebugSeed || opt::DebugExtend) {
-        std::cerr << SUBPROGRAM ": --onlyseed / --debugseed / --debugextend are diagnostics of the CPU reference and are not provided by this back end\n";
-        return EXIT_FAILURE;
-    }
+    // --debugextend is accepted and inert: in the reference its only consumer (the debugExtInfo FASTA dump) is commented out
+    // (PacBioSelfCorrectionProcess.cpp:87-98).
     PacBioSelfCorrectionParameters ecParams;
     std::cerr << "Loading BWT: " << opt::prefix + BWT_EXT << "\n" << "Loading RBWT: " << opt::prefix + RBWT_EXT << "\n";
     lrsc_index* idx = nullptr;
@@ -191,6 +194,8 @@ static int PacBioSelfCorrectionMain(int argc, char** argv)
 
     ecParams.index = idx; ecParams.devices = opt::devices; ecParams.directory = opt::directory; ecParams.p = p;
     ecParams.threads = opt::thread;
+    ecParams.DebugExtend = opt::DebugExtend; ecParams.DebugSeed = opt::DebugSeed; ecParams.OnlySeed = opt::OnlySeed;
+    if(opt::OnlySeed) BCode::load(opt::barcode);                   // reference :191
 
     {   // <out>/threshold-table (KmerThreshold.cpp:31-41,65-72)
         float thr[3 * 52];
@@ -273,11 +278,13 @@ static int indexMain(int argc, char** argv)
 
 int main(int argc, char** argv)
 {
-    if(argc <= 1) { std::cerr << "Usage: " PACKAGE_NAME " <command> [options]\nCommands: index, pbcorrect\n"; return EXIT_FAILURE; }
+    if(argc <= 1) { std::cerr << "Usage: " PACKAGE_NAME " <command> [options]\nCommands: index, pbcorrect, kmerfreq, kmercheck\n"; return EXIT_FAILURE; }
     const std::string command(argv[1]);
-    if(command == "help" || command == "--help") { std::cout << "Usage: " PACKAGE_NAME " <command> [options]\nCommands: index, pbcorrect\n"; return 0; }
+    if(command == "help" || command == "--help") { std::cout << "Usage: " PACKAGE_NAME " <command> [options]\nCommands: index, pbcorrect, kmerfreq, kmercheck\n"; return 0; }
     if(command == "pbcorrect" || command == SUBPROGRAM) return PacBioSelfCorrectionMain(argc - 1, argv + 1);
     if(command == "index") return indexMain(argc - 1, argv + 1);
+    if(command == "kmerfreq") return kmerfreqMain(argc - 1, argv + 1);
+    if(command == "kmercheck") return kmercheckMain(argc - 1, argv + 1);
     std::cerr << "Unrecognized command: " << command << "\n";
     return EXIT_FAILURE;
 }

@@ -194,6 +194,44 @@ int64_t orc_find_seeds(void* bwt, void* rbwt, const lrsc_params* p, const char* 
 }
 
 
+// What --debugseed dumps beside the seeds: the seeds removeHitchhikingSeeds dropped (seed/error/<id>.seed, LongReadProbe.cpp:220-225;
+// same 8-int records) and getSeqAttribute's ratio per position (extend/<id>.log, :170-171; NaN-free, 0 for reads shorter than k).
+int64_t orc_find_seeds_debug(void* bwt, void* rbwt, const lrsc_params* p, const char* bases, const uint64_t* off, uint32_t n_reads,
+                             uint32_t* outcast_count, int32_t* outcasts, uint64_t cap, float* ratio)
+{
+    KmerThreshold thr;
+    thr.initialize(-1, 50, p->pb_coverage);
+    const ProbeParameters pp = make_probe(static_cast<RLBwt*>(bwt), static_cast<RLBwt*>(rbwt), p, &thr);
+    uint64_t total = 0;
+    for(uint32_t r = 0; r < n_reads; ++r) {
+        const std::string seq(bases + off[r], bases + off[r + 1]);
+        KmerLog log;
+        allocateKmerLog(log, pp.pool, seq.size());
+        SeedFeature::SeedVector sv;
+        ProbeDebug dbg;
+        searchSeedsWithHybridKmers(pp, log, seq, sv, &dbg, nullptr);
+        if(ratio) for(size_t i = 0; i < seq.size(); ++i) ratio[off[r] + i] = i < dbg.ratio.size() ? dbg.ratio[i] : 0.0f;
+        outcast_count[r] = (uint32_t)dbg.outcast.size();
+        for(const auto& s : dbg.outcast) {
+            if(total >= cap) return -1;
+            int32_t* o = outcasts + total * 8;
+            o[0] = s.seedStartPos; o[1] = s.seedLen; o[2] = s.maxFixedMerFreq; o[3] = s.isRepeat ? 1 : 0;
+            o[4] = s.startBestKmerSize; o[5] = s.endBestKmerSize; o[6] = s.startKmerFreq; o[7] = s.endKmerFreq;
+            ++total;
+        }
+    }
+    return (int64_t)total;
+}
+
+// KmerThreshold::initialize(-1, end, cov, "") as `stride kmerfreq` sets it up (kmerfreq.cpp:75): out[mode*(end+2)+k]
+int orc_threshold_table_range(int cov, int end, float* out)
+{
+    KmerThreshold thr;
+    thr.initialize(-1, end, cov);
+    for(int m = 0; m < 3; ++m) for(int k = 0; k <= end + 1; ++k) out[m * (end + 2) + k] = thr.get(m, k);
+    return 0;
+}
+
 // ---- IntervalTree (PacBio/IntervalTree.cpp) -----------------------------------------------------
 void* orc_itree_build(const uint64_t* start, const uint64_t* stop, const uint64_t* value, uint64_t n)
 {

@@ -192,6 +192,27 @@ class Oracle:
         self.lib.orc_kmer_grid(bwt.h, rbwt.h, _p(bases), _p(off), off.size - 1, _p(ks), ks.size, _p(iv), _p(size), _p(cnt))
         return iv, size, cnt
 
+    def find_seeds_debug(self, bwt: "OracleBwt", rbwt: "OracleBwt", params, bases, off):
+        """What --debugseed dumps beside the seeds -> (outcast_count uint32[n_reads], outcasts int32[n,8], ratio float32[total])."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        n_reads = off.size - 1
+        cap = max(1024, int(off[-1]) // 8)
+        count = np.zeros(n_reads, dtype=np.uint32)
+        seeds = np.zeros((cap, 8), dtype=np.int32)
+        ratio = np.zeros(int(off[-1]), dtype=np.float32)
+        self.lib.orc_find_seeds_debug.restype = C.c_int64
+        n = self.lib.orc_find_seeds_debug(C.c_void_p(bwt.h), C.c_void_p(rbwt.h), C.byref(params), _p(bases), _p(off), C.c_uint32(n_reads),
+                                          _p(count), _p(seeds), C.c_uint64(cap), _p(ratio))
+        if n < 0:
+            raise RuntimeError("seed capacity too small")
+        return count, seeds[:n].copy(), ratio
+
+    def threshold_table_range(self, cov: int, end: int) -> np.ndarray:
+        out = np.zeros((3, end + 2), dtype=np.float32)
+        self.lib.orc_threshold_table_range(cov, end, _p(out))
+        return out
+
     def find_seeds(self, bwt: "OracleBwt", rbwt: "OracleBwt", params, bases, off):
         """-> (seed_count uint32[n_reads], seeds int32[n,8], attribute int8[total])."""
         bases = np.ascontiguousarray(bases, dtype=np.uint8)

@@ -11,6 +11,8 @@
 //   * KmerThreshold table                       PacBio/KmerThreshold.cpp:43-79
 //   * IntervalTree build + findOverlapping      PacBio/IntervalTree.cpp:4-48,73-91
 //   * Overlapper::extendMatch                   Thirdparty/overlapper.cpp:421-701
+//   * BCode::load / BCode::validate             PacBio/BCode.cpp:27-153 (--onlyseed, kmercheck)
+//   * KmerDistribution + compare()              Util/KmerDistribution.cpp:25-153 (kmercheck)
 //
 // Everything above BWTAlgorithms.h (findInterval, LongReadProbe, FM-extend,
 // multiple_alignment) pulls Util/HashMap.h -> generated config.h + google
@@ -27,6 +29,8 @@
 #include "KmerThreshold.h"
 #include "IntervalTree.h"
 #include "overlapper.h"
+#include "BCode.h"
+#include "KmerDistribution.h"
 
 extern "C" {
 
@@ -110,6 +114,45 @@ int ref_extend_match(const char* s1, const char* s2, int start1, int start2, int
     std::strncpy(cigar, ov.cigar.c_str(), cigar_cap - 1);
     cigar[cigar_cap - 1] = 0;
     return (int)ov.cigar.size();
+}
+
+
+// ---- BCode (PacBio/BCode.cpp) ------------------------------------------------------------------
+// validate() on one block; -1 if the reference throws (std::map::at / substr on a malformed code).
+int ref_bcode_validate(int pos, int ksize, int start, int end, const char* code, int rvc, const char* seq)
+{
+    try {
+        const BCode block(start, end, std::string(code), rvc != 0);
+        return BCode::validate(pos, ksize, block, std::string(seq)) ? 1 : 0;
+    } catch(const std::exception&) {
+        return -1;
+    }
+}
+// load() may run once per process (BCode.cpp:29-33).  Dumps the log as "qname start end rvc code\n" lines in map order.
+uint64_t ref_bcode_load_dump(const char* path, char* out, uint64_t cap)
+{
+    if(BCode::Log().empty()) BCode::load(std::string(path));
+    std::ostringstream o;
+    for(const auto& kv : BCode::Log())
+        for(const BCode& b : kv.second)
+            o << kv.first << ' ' << b.getStart() << ' ' << b.getEnd() << ' ' << (b.getRvc() ? 1 : 0) << ' ' << b.getCode() << '\n';
+    const std::string s = o.str();
+    if(out && cap >= s.size()) std::memcpy(out, s.data(), s.size());
+    return s.size();
+}
+
+// ---- KmerDistribution (Util/KmerDistribution.cpp) ------------------------------------------------
+// compare() over two frequency lists -> "total.box line" + "value.box line"
+uint64_t ref_kd_compare(const int* crt, uint64_t n_crt, const int* err, uint64_t n_err, int cov, int ksize, char* out, uint64_t cap)
+{
+    KmerDistribution c, e;
+    for(uint64_t i = 0; i < n_crt; ++i) c.add(crt[i]);
+    for(uint64_t i = 0; i < n_err; ++i) e.add(err[i]);
+    std::ostringstream t, v;
+    compare(t, v, cov, ksize, c, e);
+    const std::string s = t.str() + v.str();
+    if(out && cap >= s.size()) std::memcpy(out, s.data(), s.size());
+    return s.size();
 }
 
 } // extern "C"
