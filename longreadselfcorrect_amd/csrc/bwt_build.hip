@@ -40,8 +40,8 @@ struct MaxOp {
 __global__ __launch_bounds__(256) void text_kernel(const char* __restrict__ ascii, const uint64_t* __restrict__ off,
                                                    uint32_t n_reads, uint64_t N, int rev, uint8_t* __restrict__ T, int* bad)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if(i >= N) return;
+    // grid-stride: a launch holds fewer than 2^32 threads, the text may not
+    for(uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (uint64_t)gridDim.x * 256) {
     // read r starts at off[r] + r in T: largest r with off[r] + r <= i
     uint32_t lo = 0, hi = n_reads;
     while(hi - lo > 1) {
@@ -59,6 +59,7 @@ __global__ __launch_bounds__(256) void text_kernel(const char* __restrict__ asci
         if(c != 'A' && c != 'C' && c != 'G' && c != 'T') *bad = 1;
     }
     T[i] = code;
+    }
 }
 
 __device__ __forceinline__ uint64_t pack_key(const uint8_t* __restrict__ T, uint64_t N, uint64_t pos)
@@ -442,7 +443,7 @@ int build_bwt_device(const char* reads, const uint64_t* off, uint32_t n_reads, i
     BB_TRY(hipMemset(d_T + N, 0, 64));
     BB_TRY(hipMemcpy(d_ascii, reads, total, hipMemcpyHostToDevice));
     BB_TRY(hipMemcpy(d_off, off, ((size_t)n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(text_kernel, dim3(nblk(N)), dim3(256), 0, st, d_ascii, d_off, n_reads, N, reverse_reads, d_T, d_bad);
+    hipLaunchKernelGGL(text_kernel, dim3((unsigned)std::min<uint64_t>((N + 255) / 256, 1u << 22)), dim3(256), 0, st, d_ascii, d_off, n_reads, N, reverse_reads, d_T, d_bad);
     BB_TRY(hipGetLastError());
     int bad = 0;
     BB_TRY(hipMemcpy(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost));
