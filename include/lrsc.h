@@ -244,9 +244,6 @@ typedef struct lrsc_walk_result {
  * (*arena_used bytes); LRSC_ERR_CAPACITY if arena_cap is too small (then *arena_used = bytes needed). */
 int lrsc_extend_walks(lrsc_ctx* ctx, const char* seq, uint64_t seq_len, const lrsc_walk_desc* walks, uint32_t n,
                       lrsc_walk_result* results, char* out_arena, uint64_t arena_cap, uint64_t* arena_used);
-/* Test hook: the permutation std::sort (libstdc++ introsort, comparator a.start > b.start) leaves n
- * (key, index) pairs in -- the product's own re-implementation, run on the host. perm_out[j] = index. */
-int lrsc_debug_sort_order(const uint64_t* keys, uint32_t n, uint32_t* perm_out);
 
 /* ---- the whole per-read path ------------------------------------------------------------------------ */
 /* PacBioSelfCorrectionResult (PacBio/PacBioSelfCorrectionProcess.h:58-94) without the wall-clock timers;
@@ -352,18 +349,6 @@ int lrsc_ctx_stats(lrsc_ctx* ctx, int kernel, lrsc_kernel_stats* out);
 int lrsc_ctx_stats_reset(lrsc_ctx* ctx);
 /* Block until everything queued on the ctx stream is done. */
 int lrsc_ctx_sync(lrsc_ctx* ctx);
-
-/* ---- synthetic data (deterministic) -------------------------------- */
-/* i.i.d. uniform ACGT genome of `len` bases into out (no terminator). */
-int lrsc_synth_genome(uint64_t seed, uint64_t len, char* out);
-/* Simulated PacBio reads: template of `tmpl_len` bases at a uniform start, random strand,
- * per-template-base deletion p_del, substitution p_sub, geometric insertion with mean p_ins.
- * out_bases must hold cap bytes; out_off n_reads+1 entries.  Read i depends only on
- * (seed, first_read + i), so shards generate disjoint slices independently. */
-int lrsc_synth_reads(uint64_t seed, const char* genome, uint64_t genome_len,
-                     uint64_t first_read, uint32_t n_reads, uint32_t tmpl_len,
-                     double p_del, double p_sub, double p_ins,
-                     char* out_bases, uint64_t cap, uint64_t* out_off);
 
 const char* lrsc_strerror(int status);
 /* last detailed message for the calling thread (e.g. the HIP error string) */

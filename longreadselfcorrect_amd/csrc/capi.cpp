@@ -1009,16 +1009,6 @@ extern "C" int lrsc_batch_walk_log(lrsc_ctx* ctx, lrsc_batch* b, uint8_t* log, u
 // ---------------------------------------------------------------------------------------
 // FM-extend
 // ---------------------------------------------------------------------------------------
-extern "C" int lrsc_debug_sort_order(const uint64_t* keys, uint32_t n, uint32_t* perm_out)
-{
-    if((!keys || !perm_out) && n) return fail(LRSC_ERR_ARG, "null");
-    std::vector<SortItem> v(n);
-    for(uint32_t i = 0; i < n; ++i) { v[i].key = keys[i]; v[i].val = i; v[i].pad = 0; }
-    introsort(v.data(), (int64_t)n);
-    for(uint32_t i = 0; i < n; ++i) perm_out[i] = v[i].val;
-    return LRSC_OK;
-}
-
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 extern "C" int lrsc_extend_walks(lrsc_ctx* ctx, const char* seq, uint64_t seq_len, const lrsc_walk_desc* walks, uint32_t n,

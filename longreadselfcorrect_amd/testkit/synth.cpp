@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../include/lrsc.h"
+#include "lrsc_testkit.h"
 
 namespace {
 
