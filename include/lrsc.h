@@ -271,11 +271,11 @@ enum lrsc_read_status {
     LRSC_READ_OUTPUT_LIMIT = 6,          /* the corrected string outgrew its slot                                        */
     LRSC_READ_INTERNAL = 7               /* FM-extension returned a code the reference treats as impossible (it exits)   */
 };
-/* PacBioSelfCorrectionProcess::process for every read of the batch (PacBioSelfCorrectionProcess.cpp:23-206):
- * seeds and seed-to-seed FM-extension on the device, stitching on the host, with the ctx's parameters.
- * Piece p is out[piece_off[p] .. piece_off[p+1]).  Needs params.no_dp (the DP/MSA fallback of
- * correctByMSAlignment is not part of the product yet): LRSC_ERR_UNSUPPORTED otherwise.
- * LRSC_ERR_CAPACITY (with *n_pieces / *out_used = what is needed) if piece_cap / out_cap are too small. */
+/* PacBioSelfCorrectionProcess::process for every read of the batch (PacBioSelfCorrectionProcess.cpp:23-245): seeds, the chain of
+ * seed-to-seed FM-extensions, the DP/MSA fallback of correctByMSAlignment (unless params.no_dp) and the stitching, all on the
+ * device, with the ctx's parameters.  Piece p is out[piece_off[p] .. piece_off[p+1]).
+ * LRSC_ERR_CAPACITY (with *n_pieces / *out_used = what is needed) if piece_cap / out_cap are too small.  A read that exceeds a
+ * per-read capacity does not fail the call: see lrsc_read_result.status. */
 int lrsc_correct_reads(lrsc_ctx* ctx, const char* reads, const uint64_t* read_off, uint32_t n_reads,
                        lrsc_read_result* results, uint64_t* piece_off, uint64_t piece_cap, char* out, uint64_t out_cap,
                        uint64_t* n_pieces, uint64_t* out_used);
