@@ -133,7 +133,7 @@ LRSC_SORT_HD int64_t unguarded_partition_pivot(SortItem* a, int64_t first, int64
 
 // std::sort(a, a + n, greater-by-key)
 #ifdef __HIPCC__
-static __host__ __device__ __attribute__((noinline)) void introsort(SortItem* a, int64_t n)
+static __host__ __device__ __attribute__((noinline, unused)) void introsort(SortItem* a, int64_t n)
 #else
 inline void introsort(SortItem* a, int64_t n)
 #endif

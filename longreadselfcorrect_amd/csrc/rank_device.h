@@ -359,7 +359,9 @@ __host__ __device__ __forceinline__ void block_popc4(const typename Lay<WIDE>::R
         c[3] += __builtin_popcount(l & h & mk);
     }
 }
-template <bool WIDE>
+// updateInterval for all four bases at once: the two rank positions' blocks are loaded once, every symbol class is counted from
+// the same registers.  SKIP2: do not load the second block when both positions share one (pays where few lanes are active).
+template <bool WIDE, bool SKIP2 = false>
 __host__ __device__ __forceinline__ void update_interval_all(const StrandC<typename Lay<WIDE>::pos_t>& s, IvT<typename Lay<WIDE>::pos_t> iv,
                                                              const uint32_t* __restrict__ mtab, IvT<typename Lay<WIDE>::pos_t> out[4], uint32_t& n_blk)
 {
@@ -370,7 +372,8 @@ __host__ __device__ __forceinline__ void update_interval_all(const StrandC<typen
     const uint32_t ol = (uint32_t)(pl - bl * L::kSyms), ou = (uint32_t)(pu - bu * L::kSyms);
     typename L::Regs ra, rb;
     L::load(s.blocks, bl, ra);
-    L::load(s.blocks, bu, rb);
+    if(SKIP2) { rb = ra; if(bu != bl) L::load(s.blocks, bu, rb); }
+    else L::load(s.blocks, bu, rb);
     uint32_t pa[4], pb4[4];
     block_popc4<WIDE>(ra, mtab + ol * L::kRow, pa);
     block_popc4<WIDE>(rb, mtab + ou * L::kRow, pb4);

@@ -40,8 +40,11 @@ __device__ __forceinline__ void prepare_offset(const FmIndexDev& fm, const Stran
         if(!jumped) { st = walk_step<WIDE>(sf, sr, q[i + s], 1u << 30, st, mtab); ++s; }
         if(st.size == 5) flags5[i] = (uint8_t)((st.fwd.lo <= st.fwd.hi ? 1 : 0) | (st.rvc.lo <= st.rvc.hi ? 2 : 0));
         if(st.size == seedk) {
-            it9f[i].key = st.fwd.lo <= st.fwd.hi ? (uint64_t)st.fwd.lo : kNoKey; it9f[i].val = i; it9f[i].pad = 0;
-            it9r[i].key = st.rvc.lo <= st.rvc.hi ? (uint64_t)st.rvc.lo : kNoKey; it9r[i].val = i; it9r[i].pad = 0;
+            // pad carries the idmer's 2-bit code through the sort: the hit chains compare it instead of re-reading m_query
+            uint32_t code = 0;
+            for(uint32_t t = 0; t < seedk; ++t) code = (code << 2) | q[i + t];
+            it9f[i].key = st.fwd.lo <= st.fwd.hi ? (uint64_t)st.fwd.lo : kNoKey; it9f[i].val = i; it9f[i].pad = code;
+            it9r[i].key = st.rvc.lo <= st.rvc.hi ? (uint64_t)st.rvc.lo : kNoKey; it9r[i].val = i; it9r[i].pad = code;
         }
         if(st.size == mink && want_term) {
             P* t = term + (uint64_t)(i - trg0) * 4;
@@ -233,11 +236,15 @@ struct Walk {
         uint64_t totalcount = 0;
         int maxfreqsofleave = 0;
         const bool fv = lf.flo <= lf.fhi, rv = lf.rlo <= lf.rhi;
+        // all four bases of a strand from one pair of block loads (the reference issues eight updateIntervals, .cpp:685-700)
+        IvT<P> fo[4], ro[4];
+        if(fv) { update_interval_all<WIDE, true>(sF, IvT<P>{lf.flo, lf.fhi}, mtab, fo, n_blk); n_rank += 8; }
+        if(rv) { update_interval_all<WIDE, true>(sR, IvT<P>{lf.rlo, lf.rhi}, mtab, ro, n_blk); n_rank += 8; }
 #pragma unroll
         for(uint32_t b = 0; b < 4; ++b) {
             IvT<P> fp{lf.flo, lf.fhi}, rp{lf.rlo, lf.rhi};
-            if(fv) fp = upd(sF, b, fp);
-            if(rv) rp = upd(sR, 3u - b, rp);
+            if(fv) fp = fo[b];
+            if(rv) rp = ro[3u - b];
             ext[b].f = fp; ext[b].r = rp;
             ext[b].freq = (int)(isize(fp.lo, fp.hi) + isize(rp.lo, rp.hi));
             totalcount += (uint64_t)(int64_t)ext[b].freq;
@@ -253,12 +260,14 @@ struct Walk {
             const double kmerRatio = (double)kmerFreq / (double)maxfreqsofleave;
             const bool efv = ext[b].f.lo <= ext[b].f.hi, erv = ext[b].r.lo <= ext[b].r.hi;
             const uint32_t code5 = (uint32_t)(((lf.suf_lo << 2) | b) & 0x3FFu);
-            const bool isMatchedBy5mer = ismatchedbykmer(code5, efv, erv);
             const bool isFreqPass = kmerFreq >= IntervalSizeCutoff;
             const bool isLowCoverage = totalcount >= IntervalSizeCutoff + 2;
             const bool isRepeat = maxfreqsofleave > 100;
             const bool isHighlyRepeat = maxfreqsofleave > 150;
             const bool isLowlyRepeat = maxfreqsofleave > 50;
+            // the 5-mer test (a walk over a chain in global memory) only enters the ladder for repeats: evaluated lazily, it has no
+            // side effects (.cpp:716-733 computes it for every base)
+            const bool isMatchedBy5mer = isLowlyRepeat && ismatchedbykmer(code5, efv, erv);
             if(isMatchedBy5mer && isHighlyRepeat) kmerRatioCutoff = 0.125;
             else if(isMatchedBy5mer && isLowlyRepeat) kmerRatioCutoff = 0.2;
             else if(isFreqPass) kmerRatioCutoff = 0.25;
@@ -376,7 +385,7 @@ struct Walk {
         uint32_t jf = fv ? head9f[hb] : 0xFFFFu;
         uint32_t jr = rv ? head9r[hb] : 0xFFFFu;
         auto advance = [&](uint32_t j, const SortItem* it, const uint16_t* nx) -> uint32_t {
-            while(j != 0xFFFFu && kmer_code(it[j].val) != code9) j = nx[j];
+            while(j != 0xFFFFu && it[j].pad != code9) j = nx[j];
             return j;
         };
         jf = advance(jf, it9f, next9f);
@@ -521,7 +530,7 @@ struct Walk {
             // append in sorted order: chains keep the post-sort order of equal keys
             uint16_t tail[256];
             for(uint32_t j = 0; j < n; ++j) {
-                const uint32_t code = kmer_code(it[j].val);
+                const uint32_t code = it[j].pad;
                 const uint32_t hb = (code ^ (code >> 9)) & 255u;
                 next[j] = 0xFFFFu;
                 if(head[hb] == 0xFFFFu) head[hb] = (uint16_t)j; else next[tail[hb]] = (uint16_t)j;

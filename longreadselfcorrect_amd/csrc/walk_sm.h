@@ -595,7 +595,8 @@ struct ReadSM {
             if(exv(ex, ex_stride, b, 0) <= exv(ex, ex_stride, b, 1)) fvalid4 |= 1u << b;
             if(exv(ex, ex_stride, b, 2) <= exv(ex, ex_stride, b, 3)) rvalid4 |= 1u << b;
         }
-        uint32_t matched4 = matched_by_5mer((uint32_t)lf.suf_lo, fvalid4, rvalid4);
+        // only repeats (maxfreqsofleave > 50) look at the 5-mer test in the ladder below: skip the window scan otherwise
+        const uint32_t matched4 = maxfreqsofleave > 50 ? matched_by_5mer((uint32_t)lf.suf_lo, fvalid4, rvalid4) : 0u;
         for(uint32_t b = 0; b < 4; ++b) {
             const uint64_t kmerFreq = (uint64_t)(int64_t)freq[b];
             const double kmerRatioNotPass = 2;
