@@ -1767,6 +1767,13 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
         const double tot = c[0] + c[1] + c[2] + c[3];
         std::fprintf(stderr, "[lrsc] correct kernel lane-ticks: prepare %.1f%%, trees+root %.1f%%, extension loop %.1f%%, stitch+other %.1f%% (%.3g ticks)\n",
                      100 * c[0] / tot, 100 * c[1] / tot, 100 * c[2] / tot, 100 * c[3] / tot, tot);
+        double s8[8] = {0, 0, 0, 0, 0, 0, 0, 0}, steps = 0;
+        for(uint32_t r = 0; r < n; ++r) { for(int j = 0; j < 8; ++j) s8[j] += (double)ro[r].cyc_step[j]; steps += (double)ro[r].steps; }
+        if(steps > 0 && c[2] > 0)
+            std::fprintf(stderr, "[lrsc] extension step (%.0f ticks avg over %.3g steps): extendLeaves %.1f%% (refine %.1f%%, attempToExtend %.1f%% of which getFMIndexExtensions %.1f%%), "
+                                 "PrunedBySeedSupport %.1f%%, materialise+commit %.1f%%, isTerminated %.1f%%\n",
+                         c[2] / steps, steps, 100 * s8[0] / c[2], 100 * s8[1] / c[2], 100 * s8[2] / c[2], 100 * s8[3] / c[2], 100 * s8[4] / c[2], 100 * s8[5] / c[2],
+                         100 * s8[6] / c[2]);
     }
     std::vector<uint64_t> dst_off(n + 1, 0);
     uint64_t n_pieces = 0;

@@ -42,6 +42,8 @@ struct ReadOut {             // PacBioSelfCorrectionResult (PacBioSelfCorrection
     int32_t s_seed_len, s_end, s_end_best, s_max_fixed, s_is_repeat;
     uint32_t dp_k, dp_lq;
     int64_t dp_total_freq;       // source.maxFixedMerFreq + target.maxFixedMerFreq
+    uint64_t cyc_step[8];        // LRSC_CORRECT_PROFILE, lane kernel: ticks inside the extension step: extendLeaves (of which refine, attempToExtend,
+                                 // getFMIndexExtensions), PrunedBySeedSupport, materialise + commit, isTerminated
 };
 
 struct CorrectArgs {

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(64, OCC) void correct_reads_kernel(FmIndexDev fm, C
             FMNum = R.c[7]; DPNum = R.c[8]; seedDis = R.c[9];
             out_len = R.out_len; n_pieces = R.n_pieces;
             cyc_prep = R.cyc[0];
-        } else { R.cyc[0] = 0; R.cyc[1] = 0; R.cyc[2] = 0; R.cyc[3] = 0; R.steps = 0; }
+        } else { R.cyc[0] = 0; R.cyc[1] = 0; R.cyc[2] = 0; R.cyc[3] = 0; R.steps = 0; for(int k = 0; k < 8; ++k) R.cyc_step[k] = 0; }
 
         if(n_seeds >= 2 && rw.lq_max != 0 && !(resume && R.state == kReadDone)) {      // lq_max == 0: the host skipped this read (capacity)
             uint8_t* ws = a.workspace + rw.ws_off;
@@ -89,6 +89,7 @@ __global__ __launch_bounds__(64, OCC) void correct_reads_kernel(FmIndexDev fm, C
             W.q = q;
             W.n_rank = 0; W.n_blk = 0; W.steps = R.steps; W.error = 0; W.cyc_setup = R.cyc[1]; W.cyc_loop = R.cyc[2];
             W.profile = a.profile != 0;
+            W.prof = a.profile ? R.cyc_step : nullptr;
             uint8_t* dpq = ws + rw.o_dpq;                                          // the parked DP query lives here between launches
 
             // source = pieceVec.back(): the SeedFeature fields the loop reads (SeedFeature.h:22-45)

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(64, 2) void walk_extend_kernel(FmIndexDev fm, Exten
         W.pathw = ww.pathw;
         W.rpaths = W.paths + (uint64_t)32 * ww.pathw;
         W.results = reinterpret_cast<WalkResultRec*>(ws + ww.o_results);
-        W.n_rank = 0; W.n_blk = 0; W.steps = 0; W.error = 0; W.cyc_setup = 0; W.cyc_loop = 0;
+        W.n_rank = 0; W.n_blk = 0; W.steps = 0; W.error = 0; W.cyc_setup = 0; W.cyc_loop = 0; W.prof = nullptr; W.profile = false;
 
         WalkOut& o = a.out[w];
         uint32_t len = 0, mi = 0;

@@ -135,6 +135,9 @@ struct Walk {
     uint32_t n_rank, n_blk;
     uint64_t steps;
     uint64_t cyc_setup, cyc_loop;     // profiling: ticks spent building the trees/root and in the extension loop
+    uint64_t* prof;                   // profiling: ReadOut::cyc_step of the read, or nullptr
+    __device__ __forceinline__ uint64_t tick() const { return prof ? __builtin_readcyclecounter() : 0; }
+    __device__ __forceinline__ void tock(int k, uint64_t t0) { if(prof) prof[k] += __builtin_readcyclecounter() - t0; }
     int error;
 
     __device__ __forceinline__ IvT<P> upd(const StrandC<P>& s, uint32_t c, IvT<P> iv) { n_rank += 2; return update_interval<WIDE>(s, c, iv, mtab, n_blk); }
@@ -168,11 +171,25 @@ struct Walk {
             Leaf<P>& lf = leaves[j];
             // startkmer = last Lw chars of the suffix of length U; Fwd = findInterval(BWT, startkmer) walks it from
             // its last character backwards; Rvc = findInterval(RBWT, complement(startkmer)) likewise
-            IvT<P> f = init_interval<P>(sR, suf_char(lf, U, U - 1));
-            IvT<P> r = init_interval<P>(sF, 3u - suf_char(lf, U, U - 1));
-            n_rank += 2;
+            // The pair is findBiInterval of x = revcomp(startkmer) with the strands' roles swapped (f walks the bwt with c, r the
+            // rbwt with 3 - c, both from the k-mer's last character backwards), so a k-mer table entry of x's first characters
+            // -- same early-exit semantics per strand -- replaces that many dependent rank steps.
+            IvT<P> f, r;
             bool fb = false, rb = false;
-            for(uint32_t t = 1; t < Lw; ++t) {
+            uint32_t t1 = 1;
+            {
+                WalkState<P> ts = walk_init<P>();
+                const uint32_t tk = table_start<WIDE>(*fm, [&](uint32_t t) { return 3u - suf_char(lf, U, U - 1 - t); }, Lw, ts);
+                if(tk != 0) {
+                    f = ts.rvc; r = ts.fwd; fb = ts.rvc_broken; rb = ts.fwd_broken; t1 = tk;
+                } else {
+                    f = init_interval<P>(sR, suf_char(lf, U, U - 1));
+                    r = init_interval<P>(sF, 3u - suf_char(lf, U, U - 1));
+                    n_rank += 2;
+                }
+            }
+            for(uint32_t t = t1; t < Lw; ++t) {
+                if(fb && rb) break;
                 const uint32_t c = suf_char(lf, U, U - 1 - t);
                 if(!fb) { f = upd(sR, c, f); fb = f.lo > f.hi; }
                 if(!rb) { r = upd(sF, 3u - c, r); rb = r.lo > r.hi; }
@@ -312,7 +329,9 @@ struct Walk {
             while(count < 2) {
                 if(count == 1 && !(cur[i].localErr == minimumErrorRate && n_cur > 1)) break;
                 uint64_t tc;
+                const uint64_t tg = tick();
                 mask = getFMIndexExtensions(cur[i], ext, tc);
+                tock(3, tg);
                 if(mask != 0) break;
                 min_SA_threshold--;
                 count++;
@@ -343,8 +362,12 @@ struct Walk {
     __device__ void extendLeaves()
     {
         n_nxt = 0;
+        uint64_t t = tick();
         if(currentKmerSize > maxOverlap) refineSAInterval(cur, n_cur, maxOverlap);
+        tock(1, t);
+        t = tick();
         attempToExtend();
+        tock(2, t);
         if(error) return;
         if(n_nxt == 0) {                                    // level 1: reduce the k-mer size
             const uint64_t LowerBound = (currentKmerSize - 2) > minOverlap ? (currentKmerSize - 2) : minOverlap;
@@ -596,9 +619,14 @@ struct Walk {
     __device__ void step_body()
     {
         {
+            uint64_t t = tick();
             extendLeaves();
+            tock(0, t);
             if(error) return;
+            t = tick();
             PrunedBySeedSupport();
+            tock(4, t);
+            t = tick();
             uint32_t survivors = 0;
             for(uint32_t c = 0; c < n_nxt; ++c) survivors += nxt[c].alive;
             ++steps;
@@ -655,11 +683,14 @@ struct Walk {
             // m_leaves = newLeaves
             for(uint32_t i = 0; i < w; ++i) cur[i] = nxt[i];
             n_cur = w;
+            tock(5, t);
+            t = tick();
             if(currentLength >= minLength)
                 for(uint32_t i = 0; i < n_cur; ++i) {
                     terminated_leaf(cur[i], paths + (uint64_t)cur[i].path * pathw, cur[i].path_len, -1);
                     if(error) return;
                 }
+            tock(6, t);
         }
     }
 
