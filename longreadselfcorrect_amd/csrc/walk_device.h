@@ -678,7 +678,8 @@ struct Walk {
                 rings[(uint64_t)ch.ring * 100 + (ch.hist_size - 1) % 100] = ch.globalErr;     // GlobalErrorRateRecord.push_back
                 path_set(paths + (uint64_t)ch.path * pathw, ch.path_len, ch.ext);
                 ch.path_len++;
-                nxt[w++] = ch;
+                if(w != c) nxt[w] = ch;                       // compaction; a survivor that already sits in place is not copied onto itself
+                ++w;
             }
             // m_leaves = newLeaves
             for(uint32_t i = 0; i < w; ++i) cur[i] = nxt[i];
