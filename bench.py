@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--reads", type=int, default=100_000, help="reads per GPU (= index reads on rank 0)")
     ap.add_argument("--read-len", type=int, default=10_000)
     ap.add_argument("--reads-per-step", type=int, default=0,
-                    help="reads of one step's resident sub-batch (0 = stage default: all reads for `seeds`; 20000 otherwise, so that the driver's ""--steps 20 --warmup 5 fits its 600 s: a correct step is latency-bound, see DESIGN.md section 4)")
+                    help="reads of one step's resident sub-batch (0 = stage default: all reads for `seeds`; 50000 otherwise = half of the rank's shard, so that the driver's ""--steps 20 --warmup 5 fits its 600 s, see DESIGN.md section 4a)")
     ap.add_argument("--streams", type=int, default=0,
                     help="correct stages: a step's sub-batch is cut into this many parts, corrected concurrently by one host thread + "
                          "ctx (HIP stream) each, so that the DP rounds of one part overlap the extension of the others "
@@ -141,7 +141,7 @@ def main():
     else:
         bases, off = api.synth_reads(0x5EED0002, genome, n_reads, args.read_len,
                                      first_read=lrdist.weak_shard_first_read(rank, n_reads))
-    per_step = args.reads_per_step or (n_reads if args.stage == "seeds" else 20_000)
+    per_step = args.reads_per_step or (n_reads if args.stage == "seeds" else 50_000)
     per_step = max(1, min(per_step, n_reads))
     n_streams = 1 if args.stage == "seeds" else max(1, args.streams or 1)
     cuts = list(range(0, n_reads, per_step)) + [n_reads]
@@ -247,10 +247,11 @@ def main():
         pmc = REPO / "profiles" / "r02_pmc" / "traffic.json"
         if pmc.exists():
             pj = json.loads(pmc.read_text())
-            if pj.get("reads_per_launch") == batches[0].n_reads and pj.get("index_reads") == n_reads and pj.get("read_len") == args.read_len:
-                roof["traffic"] = pj["traffic_bytes_per_launch"] / 1e9
-                roof["traffic_unit"] = "GB per launch (separate rocprofv3 --pmc passes, corrected as MI355X_MICROARCH.md prescribes)"
-                roof["traffic_source"] = pj["source"]
+            for shape in pj.get("shapes", [pj]):
+                if shape.get("reads_per_launch") == batches[0].n_reads and shape.get("index_reads") == n_reads and shape.get("read_len") == args.read_len:
+                    roof["traffic"] = shape["traffic_bytes_per_launch"] / 1e9
+                    roof["traffic_unit"] = "GB per launch (separate rocprofv3 --pmc passes, corrected as MI355X_MICROARCH.md prescribes)"
+                    roof["traffic_source"] = shape["source"]
         value = total_bases / elapsed_max / 1e6
         stage_ms = {"kmer_grid": Agg(K_GRID).total_ms / args.steps, "seed_scan_group": Agg(K_SEEDS).total_ms / args.steps}
         if args.stage != "seeds":
