@@ -79,6 +79,7 @@ __global__ __launch_bounds__(64, OCC) void correct_reads_kernel(FmIndexDev fm, C
             W.term = term;
             W.cur = reinterpret_cast<Leaf<P>*>(ws + rw.o_leaves);
             W.nxt = W.cur + 32;
+            W.leaf_small = W.cur;
             W.rings = reinterpret_cast<double*>(ws + rw.o_rings);
             W.paths = reinterpret_cast<uint32_t*>(ws + rw.o_paths);
             W.pathw = rw.pathw;

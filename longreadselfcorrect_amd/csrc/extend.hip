@@ -95,6 +95,7 @@ __global__ __launch_bounds__(64, 2) void walk_extend_kernel(FmIndexDev fm, Exten
         W.n_term = ww.trg_len >= a.min_overlap ? ww.trg_len - a.min_overlap + 1 : 0;
         W.cur = reinterpret_cast<Leaf<P>*>(ws + ww.o_leaves);
         W.nxt = W.cur + 32;
+        W.leaf_small = W.cur;
         W.rings = reinterpret_cast<double*>(ws + ww.o_rings);
         W.paths = reinterpret_cast<uint32_t*>(ws + ww.o_paths);
         W.pathw = ww.pathw;

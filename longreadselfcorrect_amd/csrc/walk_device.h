@@ -58,7 +58,7 @@ __device__ __forceinline__ void prepare_offset(const FmIndexDev& fm, const Stran
 // 2. the walk
 // ---------------------------------------------------------------------------------------
 template <class P>
-struct Leaf {                         // SAIOverlapNode3 + leafInfo, flattened
+struct alignas(16) Leaf {             // SAIOverlapNode3 + leafInfo, flattened; 16-byte aligned: leaf copies are dwordx4 moves
     P flo, fhi, rlo, rhi;             // fwdInterval (rbwt), rvcInterval (bwt)
     P tflo, tfhi, trlo, trhi;         // SelectFreqsOfrange's per-leaf scratch intervals (maxKmerArray)
     uint64_t suf_lo, suf_hi;          // last 64 characters of the path, 2 bits each, newest in the low bits
@@ -125,13 +125,15 @@ struct Walk {
     const uint8_t* flags5;
     const P* term;
     uint32_t n_term;
+    uint64_t tmask0, tmask1;          // 128-bit filter over the target seed's minOverlap-mers (hash of their last <= 16 characters)
     Leaf<P>* cur;  uint32_t n_cur;
+    Leaf<P>* leaf_small;              // the 32-slot leaf buffer (the other one holds kMaxChildren); cur / nxt swap between them
     Leaf<P>* nxt;  uint32_t n_nxt;
     double* rings;                    // [32][100]
     uint32_t* paths;  uint32_t pathw; // [32][pathw]
     uint32_t* rpaths;                 // [kMaxResults][pathw]
     WalkResultRec* results; uint32_t n_results;
-    uint8_t ring_free[32], path_free[32]; uint32_t n_ring_free, n_path_free;
+    uint32_t ring_free, path_free;    // bit s: ring / path slot s is free (slot 0 belongs to the root's lineage)
     uint32_t n_rank, n_blk;
     uint64_t steps;
     uint64_t cyc_setup, cyc_loop;     // profiling: ticks spent building the trees/root and in the extension loop
@@ -299,8 +301,8 @@ struct Walk {
 
     __device__ void free_leaf_slots(const Leaf<P>& lf)
     {
-        ring_free[n_ring_free++] = (uint8_t)lf.ring;
-        path_free[n_path_free++] = (uint8_t)lf.path;
+        ring_free |= 1u << lf.ring;
+        path_free |= 1u << lf.path;
     }
 
     // ---- attempToExtend (.cpp:373-465) + updateLeaves (:468-488) -------------------------------------------
@@ -498,6 +500,15 @@ struct Walk {
     __device__ __noinline__ void terminated_leaf(Leaf<P>& lf, const uint32_t* pw, uint32_t plen, int extra)
     {
         const bool fvalid = lf.flo <= lf.fhi, rvalid = lf.rlo <= lf.rhi;
+        // A non-empty interval of a k-mer K lies inside the interval of a k-mer w with |w| <= |K| only if K ends with w (fwd strand:
+        // reverse(w) is a prefix of reverse(K); rvc strand: revcomp(w) is a prefix of revcomp(K)).  So if no target minOverlap-mer
+        // hashes like the leaf's last characters, the scan below cannot hit: skip its loads.
+        if(currentKmerSize >= minOverlap) {
+            const uint32_t L = minOverlap < 16 ? (uint32_t)minOverlap : 16u;
+            const uint32_t code = (uint32_t)(lf.suf_lo & (L >= 16 ? 0xFFFFFFFFull : ((1ull << (2 * L)) - 1ull)));
+            const uint32_t h = (code * 0x9E3779B1u) >> 25;
+            if((((h < 64 ? tmask0 : tmask1) >> (h & 63u)) & 1ull) == 0) return;
+        }
         const uint64_t i0 = (uint64_t)(lf.res_second > 0 ? lf.res_second : 0);
         int hit = -1;
         for(uint64_t i = i0; i <= (uint64_t)trg_len - (int)minOverlap; i++) {
@@ -574,9 +585,22 @@ struct Walk {
             head5[code] = (uint16_t)i;
         }
 
+        // filter for isTerminated: a leaf can only be contained in the interval of a target k-mer it ends with
+        {
+            tmask0 = 0; tmask1 = 0;
+            const uint32_t L = minOverlap < 16 ? (uint32_t)minOverlap : 16u;
+            const uint32_t trg0 = initk + path_len;
+            for(uint32_t i = 0; i < n_term; ++i) {
+                uint32_t code = 0;
+                const uint8_t* p = q + trg0 + i + (uint32_t)minOverlap - L;
+                for(uint32_t t = 0; t < L; ++t) code = (code << 2) | p[t];
+                const uint32_t h = (code * 0x9E3779B1u) >> 25;
+                if(h < 64) tmask0 |= 1ull << h; else tmask1 |= 1ull << (h - 64);
+            }
+        }
+
         // --- root (initialRootNode, .cpp:108-124; leafInfo ctor, .h:156-171) ---
-        n_ring_free = 0; n_path_free = 0;
-        for(uint32_t s = 32; s-- > 1;) { ring_free[n_ring_free++] = (uint8_t)s; path_free[n_path_free++] = (uint8_t)s; }
+        ring_free = 0xFFFFFFFEu; path_free = 0xFFFFFFFEu;
         Leaf<P>& root = cur[0];
         root.suf_lo = 0; root.suf_hi = 0;
         for(uint32_t t = 0; t < initk; ++t) suf_push(root, q[t]);
@@ -645,24 +669,18 @@ struct Walk {
             }
             // materialise the survivors: the first surviving child of a parent takes over its ring and path
             // in place (SAINode::extend), further ones get copies (createChild)
-            uint8_t first_child[32];
-            for(uint32_t i = 0; i < n_cur; ++i) first_child[i] = 0xFF;
-            for(uint32_t c = 0; c < n_nxt; ++c)
-                if(nxt[c].alive && first_child[nxt[c].parent] == 0xFF) first_child[nxt[c].parent] = (uint8_t)(c & 0xFF);
-            bool has_child[32];
-            for(uint32_t i = 0; i < n_cur; ++i) { has_child[i] = false; }
-            for(uint32_t c = 0; c < n_nxt; ++c) if(nxt[c].alive) has_child[nxt[c].parent] = true;
-            for(uint32_t i = 0; i < n_cur; ++i) if(!has_child[i]) free_leaf_slots(cur[i]);
+            uint32_t has_child = 0;                         // bit i: leaf i of cur[] has a surviving child (n_cur <= 32)
+            for(uint32_t c = 0; c < n_nxt; ++c) if(nxt[c].alive) has_child |= 1u << nxt[c].parent;
+            for(uint32_t i = 0; i < n_cur; ++i) if(!((has_child >> i) & 1u)) free_leaf_slots(cur[i]);
             // copies first (they read the parent's buffers before the in-place child appends to them)
-            bool seen[32];
-            for(uint32_t i = 0; i < n_cur; ++i) seen[i] = false;
+            uint32_t seen = 0;
             for(uint32_t c = 0; c < n_nxt; ++c) {
                 Leaf<P>& ch = nxt[c];
                 if(!ch.alive) continue;
                 const Leaf<P>& par = cur[ch.parent];
-                if(!seen[ch.parent]) { seen[ch.parent] = true; ch.ring = par.ring; ch.path = par.path; continue; }
-                ch.ring = ring_free[--n_ring_free];
-                ch.path = path_free[--n_path_free];
+                if(!((seen >> ch.parent) & 1u)) { seen |= 1u << ch.parent; ch.ring = par.ring; ch.path = par.path; continue; }
+                ch.ring = (uint16_t)__builtin_ctz(ring_free); ring_free &= ring_free - 1u;     // survivors <= 32 slots: never empty here
+                ch.path = (uint16_t)__builtin_ctz(path_free); path_free &= path_free - 1u;
                 const double* src = rings + (uint64_t)par.ring * 100;
                 double* dst = rings + (uint64_t)ch.ring * 100;
                 for(uint32_t k = 0; k < 100; ++k) dst[k] = src[k];
@@ -681,8 +699,10 @@ struct Walk {
                 if(w != c) nxt[w] = ch;                       // compaction; a survivor that already sits in place is not copied onto itself
                 ++w;
             }
-            // m_leaves = newLeaves
-            for(uint32_t i = 0; i < w; ++i) cur[i] = nxt[i];
+            // m_leaves = newLeaves: the two leaf buffers trade places when the old `cur` region (32 or kMaxChildren slots) can take
+            // the next step's children (4 per survivor); otherwise the survivors are copied down as before
+            if(4u * w <= (cur == leaf_small ? 32u : kMaxChildren)) { Leaf<P>* t2 = cur; cur = nxt; nxt = t2; }
+            else for(uint32_t i = 0; i < w; ++i) cur[i] = nxt[i];
             n_cur = w;
             tock(5, t);
             t = tick();
