@@ -76,7 +76,9 @@ def main():
     ap.add_argument("--streams", type=int, default=0,
                     help="correct stages: a step's sub-batch is cut into this many parts, corrected concurrently by one host thread + "
                          "ctx (HIP stream) each, so that the DP rounds of one part overlap the extension of the others "
-                         "(default 1: on one GPU the parts contend for the same wavefront slots and the step gets slower)")
+                         "(default 2 with GPU_MAX_HW_QUEUES=16: measured 32.6 vs 28.8 Mbases/s for 1 part; with the runtime's default of 4 "
+                         "hardware queues the streams of the two parts queue behind each other's persistent kernels and 2 parts are slower; "
+                         "3 and 4 parts are slower again: the persistent kernels contend for wavefront slots)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 disables it and parity_sample)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="oracle threads of the cpu_baseline leg (0 = all host cores of this process)")
     ap.add_argument("--stage", choices=list(STAGE_INFO), default="correct",
@@ -85,6 +87,10 @@ def main():
     args = ap.parse_args()
     sinfo = STAGE_INFO[args.stage]
 
+    # The two concurrent parts of a step use ~10 HIP streams between them (main + yield + MSA side streams each); the ROCm runtime
+    # multiplexes streams onto 4 hardware queues by default, where a part's short kernels queue behind the other part's persistent
+    # correction kernel.  Must be set before the runtime initialises.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     import torch
     import torch.distributed as dist
 
@@ -143,7 +149,7 @@ def main():
                                      first_read=lrdist.weak_shard_first_read(rank, n_reads))
     per_step = args.reads_per_step or (n_reads if args.stage == "seeds" else 50_000)
     per_step = max(1, min(per_step, n_reads))
-    n_streams = 1 if args.stage == "seeds" else max(1, args.streams or 1)
+    n_streams = 1 if args.stage == "seeds" else max(1, args.streams or 2)
     cuts = list(range(0, n_reads, per_step)) + [n_reads]
     if len(cuts) > 2 and cuts[-1] - cuts[-2] < per_step // 2:      # fold a short last sub-batch into the one before it
         del cuts[-2]
