@@ -204,9 +204,10 @@ __global__ __launch_bounds__(64, OCC) void correct_reads_kernel(FmIndexDev fm, C
                     for(int t = 0; t < k; ++t) q[k + interval + t] = (uint8_t)(3 - tail[k - 1 - t]);
                 }
                 // constructor's bulk part (.cpp:82-94,127-152)
-                for(uint32_t i = 0; i < Lq; ++i)
-                    prepare_offset<WIDE>(fm, W.sF, W.sR, mtab, q, i, Lq, (uint32_t)(k + interval), a.seed_size, a.min_overlap, W.it9f,
-                                         W.it9r, flags5, term, W.n_rank, W.n_blk);
+                if(!prepare_all_from_tables<WIDE>(fm, q, Lq, (uint32_t)(k + interval), a.seed_size, a.min_overlap, W.it9f, W.it9r, flags5, term))
+                    for(uint32_t i = 0; i < Lq; ++i)
+                        prepare_offset<WIDE>(fm, W.sF, W.sR, mtab, q, i, Lq, (uint32_t)(k + interval), a.seed_size, a.min_overlap, W.it9f,
+                                             W.it9r, flags5, term, W.n_rank, W.n_blk);
                 W.Lq = Lq; W.initk = (uint32_t)k; W.path_len = (uint32_t)interval; W.trg_len = (uint32_t)trg_len; W.dis = interval;
                 W.maxOverlap = (uint32_t)k + 2;
                 W.min_SA_threshold = (uint64_t)min_SA;

@@ -54,6 +54,70 @@ __device__ __forceinline__ void prepare_offset(const FmIndexDev& fm, const Stran
     n_rank += st.n_rank; n_blk += st.n_blk;
 }
 
+// The same for every offset of m_query at once, when k-mer tables of exactly the three emitted sizes exist (the normal
+// configuration: 5, idmer = 9, minOverlap = 13): every emit is one table entry, so a rolling 2-bit window supplies the three
+// table indexes from ONE character load per offset (the generic path re-reads 5 + 9 + 13 characters per offset).
+template <bool WIDE>
+__device__ __forceinline__ int ktab_of(const FmIndexDev& fm, uint32_t k)
+{
+    int t = -1;
+    if(fm.ktab[0].k == k) t = 0;
+    if(fm.ktab[1].k == k) t = 1;
+    if(fm.ktab[2].k == k) t = 2;
+    if(fm.ktab[3].k == k) t = 3;
+    if(fm.ktab[4].k == k) t = 4;
+    return t;
+}
+template <bool WIDE>
+__device__ __forceinline__ void ktab_entry(const FmIndexDev& fm, int t, uint32_t code, typename Lay<WIDE>::pos_t e[4])
+{
+    using P = typename Lay<WIDE>::pos_t;
+    const void* tabv = t == 0 ? fm.ktab[0].entries : t == 1 ? fm.ktab[1].entries : t == 2 ? fm.ktab[2].entries
+                     : t == 3 ? fm.ktab[3].entries : fm.ktab[4].entries;
+    if(WIDE) {
+        const uint4* tp = reinterpret_cast<const uint4*>(tabv) + (uint64_t)code * 2;
+        const uint4 a = tp[0], b = tp[1];
+        e[0] = (P)(((uint64_t)a.y << 32) | a.x); e[1] = (P)(((uint64_t)a.w << 32) | a.z);
+        e[2] = (P)(((uint64_t)b.y << 32) | b.x); e[3] = (P)(((uint64_t)b.w << 32) | b.z);
+    } else {
+        const uint4 a = reinterpret_cast<const uint4*>(tabv)[code];
+        e[0] = (P)a.x; e[1] = (P)a.y; e[2] = (P)a.z; e[3] = (P)a.w;
+    }
+}
+template <bool WIDE>
+__device__ __noinline__ bool prepare_all_from_tables(const FmIndexDev& fm, const uint8_t* __restrict__ q, uint32_t Lq, uint32_t trg0, uint32_t seedk,
+                                                     uint32_t mink, SortItem* it9f, SortItem* it9r, uint8_t* flags5, typename Lay<WIDE>::pos_t* term)
+{
+    using P = typename Lay<WIDE>::pos_t;
+    if(seedk <= 5 || mink <= seedk || mink > 16) return false;
+    const int t5 = ktab_of<WIDE>(fm, 5), t9 = ktab_of<WIDE>(fm, seedk), tm = ktab_of<WIDE>(fm, mink);
+    if(t5 < 0 || t9 < 0 || tm < 0) return false;
+    const uint32_t m5 = (1u << 10) - 1u, m9 = (1u << (2 * seedk)) - 1u, mm = mink >= 16 ? 0xFFFFFFFFu : (1u << (2 * mink)) - 1u;
+    // window = characters [i, i + mink) of m_query, newest in the low bits (zeros past the end)
+    uint32_t win = 0;
+    for(uint32_t t = 0; t + 1 < mink; ++t) win = (win << 2) | (t < Lq ? (uint32_t)q[t] : 0u);
+    for(uint32_t i = 0; i < Lq; ++i) {
+        win = ((win << 2) | (i + mink - 1 < Lq ? (uint32_t)q[i + mink - 1] : 0u)) & mm;
+        P e[4];
+        if(i + 5 <= Lq) {
+            ktab_entry<WIDE>(fm, t5, (win >> (2 * (mink - 5))) & m5, e);
+            flags5[i] = (uint8_t)((e[0] <= e[1] ? 1 : 0) | (e[2] <= e[3] ? 2 : 0));
+        }
+        if(i + seedk <= Lq) {
+            const uint32_t code = (win >> (2 * (mink - seedk))) & m9;
+            ktab_entry<WIDE>(fm, t9, code, e);
+            it9f[i].key = e[0] <= e[1] ? (uint64_t)e[0] : kNoKey; it9f[i].val = i; it9f[i].pad = code;
+            it9r[i].key = e[2] <= e[3] ? (uint64_t)e[2] : kNoKey; it9r[i].val = i; it9r[i].pad = code;
+        }
+        if(i >= trg0 && i + mink <= Lq) {
+            ktab_entry<WIDE>(fm, tm, win, e);
+            P* t = term + (uint64_t)(i - trg0) * 4;
+            t[0] = e[0]; t[1] = e[1]; t[2] = e[2]; t[3] = e[3];
+        }
+    }
+    return true;
+}
+
 // ---------------------------------------------------------------------------------------
 // 2. the walk
 // ---------------------------------------------------------------------------------------
