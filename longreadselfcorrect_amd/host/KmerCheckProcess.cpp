@@ -36,7 +36,10 @@ std::vector<KmerCheckResult> KmerCheckProcess::process_batch(const std::vector<S
         kmers.clear();
         for(size_t i = 0; i < items.size(); ++i) {
             const std::string& seq = items[i].read.seq;
-            for(const BCode& block : BCode::Log()[items[i].read.id])
+            // find(), not operator[]: several workers read the log concurrently and must not insert into it
+            const auto entry = BCode::Log().find(items[i].read.id);
+            if(entry == BCode::Log().end()) continue;
+            for(const BCode& block : entry->second)
                 for(int pos = block.getStart(); pos <= block.getEnd() - k; ++pos) {          // scan(), reference :25-27
                     if(pos < 0 || (size_t)pos + (size_t)k > seq.size()) {
                         std::cerr << "kmercheck: block " << block.getStart() << "-" << block.getEnd() << " of " << items[i].read.id

@@ -59,8 +59,8 @@ static const char* CORRECT_USAGE_MESSAGE =
     "      --onlyseed                       Only search seeds file for each reads (default: false)\n"
     "      --nodp                           Don't use dp (default: false)\n"
     "      --split                          Split the uncorrected reads (default: false)\n"
-    "      --devices=LIST                   HIP devices to use, one worker each, e.g. 0,1,2,3; a device may be listed twice\n"
-    "                                       (0,0: two batches in flight on it, ~13 % more throughput) (default: 0)\n"
+    "      --devices=LIST                   HIP devices to use, e.g. 0,1,2,3 (default: 0)\n"
+    "      --workers-per-device=N           batches in flight per device (default: 2; two are ~13 % faster than one)\n"
     "      --batch=N                        Reads per device batch (default: 100000)\n"
     "\nReport bugs to " PACKAGE_BUGREPORT "\n\n";
 
@@ -73,11 +73,12 @@ static int startKmerLen = 19, nextTarget = 1, maxLeaves = 32, idmerLen = 9, minK
 static bool Split = false, DebugExtend = false, DebugSeed = false, OnlySeed = false, NoDp = false, Manual = false, Adjust = false;
 static std::array<int, 3> offset = {{0, 0, 0}};
 static std::vector<int> devices(1, 0);
+static int workersPerDevice = 2;
 static size_t batch = 100000;
 }
 
 static const char* shortopts = "t:p:o:b:c:e:k:u:r:n:l:i:s:g:m:v";
-enum { OPT_HELP = 1, OPT_VERSION, OPT_SPLIT, OPT_FIRST, OPT_DEBUGEXTEND, OPT_DEBUGSEED, OPT_ONLYSEED, OPT_NODP, OPT_DEVICES, OPT_BATCH };
+enum { OPT_HELP = 1, OPT_VERSION, OPT_SPLIT, OPT_FIRST, OPT_DEBUGEXTEND, OPT_DEBUGSEED, OPT_ONLYSEED, OPT_NODP, OPT_DEVICES, OPT_BATCH, OPT_WORKERS };
 static const struct option longopts[] = {
     {"thread", required_argument, nullptr, 't'},       {"prefix", required_argument, nullptr, 'p'},
     {"output", required_argument, nullptr, 'o'},       {"barcode", required_argument, nullptr, 'b'},
@@ -91,7 +92,8 @@ static const struct option longopts[] = {
     {"split", no_argument, nullptr, OPT_SPLIT},        {"debugextend", no_argument, nullptr, OPT_DEBUGEXTEND},
     {"debugseed", no_argument, nullptr, OPT_DEBUGSEED}, {"onlyseed", no_argument, nullptr, OPT_ONLYSEED},
     {"nodp", no_argument, nullptr, OPT_NODP},          {"devices", required_argument, nullptr, OPT_DEVICES},
-    {"batch", required_argument, nullptr, OPT_BATCH},  {nullptr, 0, nullptr, 0}};
+    {"batch", required_argument, nullptr, OPT_BATCH},  {"workers-per-device", required_argument, nullptr, OPT_WORKERS},
+    {nullptr, 0, nullptr, 0}};
 
 static void lrscOrDie(int st, const char* what)
 {
@@ -138,6 +140,7 @@ static void parsePacBioSelfCorrectionOptions(int argc, char** argv)
                 break;
             }
             case OPT_BATCH: arg >> opt::batch; break;
+            case OPT_WORKERS: arg >> opt::workersPerDevice; break;
             default: die = true; break;
         }
     }
@@ -167,7 +170,7 @@ static void parsePacBioSelfCorrectionOptions(int argc, char** argv)
     if(opt::genome != 5 && opt::genome != 10 && opt::genome != 100) { std::cerr << SUBPROGRAM ": invalid genome size: " << opt::genome << ", must be (5/10/100)[m]\n"; die = true; }
     if(opt::mode < 0 || opt::mode > 2) { std::cerr << SUBPROGRAM ": invalid mode: " << opt::mode << ", must be (0/1/2)\n"; die = true; }
     if(opt::OnlySeed && opt::barcode.empty()) { std::cerr << SUBPROGRAM ": no barcode\n"; die = true; }
-    if(opt::devices.empty() || opt::batch == 0) { std::cerr << SUBPROGRAM ": invalid --devices / --batch\n"; die = true; }
+    if(opt::devices.empty() || opt::batch == 0 || opt::workersPerDevice < 1 || opt::workersPerDevice > 8) { std::cerr << SUBPROGRAM ": invalid --devices / --batch / --workers-per-device\n"; die = true; }
     if(die) { std::cerr << "\n" << CORRECT_USAGE_MESSAGE; exit(EXIT_FAILURE); }
     opt::readsFile = argv[optind++];
 }
@@ -193,7 +196,10 @@ static int PacBioSelfCorrectionMain(int argc, char** argv)
     p.idmer_len = opt::idmerLen; p.min_kmer_len = opt::minKmerLen; p.mode = opt::mode; p.manual = opt::Manual ? 1 : 0;
     p.split = opt::Split ? 1 : 0; p.no_dp = opt::NoDp ? 1 : 0;
 
-    ecParams.index = idx; ecParams.devices = opt::devices; ecParams.directory = opt::directory; ecParams.p = p;
+    // one framework worker (host thread + lrsc_ctx) per entry: every device is listed workersPerDevice times, device-major order
+    std::vector<int> workers;
+    for(int w = 0; w < opt::workersPerDevice; ++w) for(int d : opt::devices) workers.push_back(d);
+    ecParams.index = idx; ecParams.devices = workers; ecParams.directory = opt::directory; ecParams.p = p;
     ecParams.threads = opt::thread;
     ecParams.DebugExtend = opt::DebugExtend; ecParams.DebugSeed = opt::DebugSeed; ecParams.OnlySeed = opt::OnlySeed;
     if(opt::OnlySeed) BCode::load(opt::barcode);                   // reference :191
@@ -214,7 +220,7 @@ static int PacBioSelfCorrectionMain(int argc, char** argv)
               << "small kmer size:\t" << opt::minKmerLen << "\n"
               << "max leaves:\t" << opt::maxLeaves << "\n"
               << "max depth:\t1.2~0.8* (length between two seeds +- 20)" << "\n"
-              << "devices:\t" << opt::devices.size() << "\n";
+              << "devices:\t" << opt::devices.size() << " x " << opt::workersPerDevice << " workers\n";
 
     SequenceProcessFramework::processSequences<SequenceWorkItem, PacBioSelfCorrectionResult, PacBioSelfCorrectionProcess,
                                                PacBioSelfCorrectionPostProcess, PacBioSelfCorrectionParameters>(
