@@ -34,12 +34,28 @@ def test_help_and_version_exit_zero(stride):
     (["-p", "x", "-o", "/tmp/lrsc_cli_t", "-e", "1.5", "a.fa"], "invalid error rate: 1.5, must be 0 ~ 1"),
     (["-p", "x", "-o", "/tmp/lrsc_cli_t", "-m", "3", "a.fa"], "invalid mode: 3, must be (0/1/2)"),
     (["-p", "x", "-o", "/tmp/lrsc_cli_t", "--onlyseed", "a.fa"], "PacBioSelfCorrection: no barcode"),
+    (["-p", "x", "-o", "/tmp/lrsc_cli_t", "--workers-per-device", "0", "a.fa"], "invalid --devices / --batch / --workers-per-device"),
 ])
 def test_bad_arguments_print_message_and_usage_and_fail(stride, args, msg):
     # reference: message on stderr, then usage, exit(EXIT_FAILURE) (StriDe/PacBioSelfCorrection.cpp:318-430)
     r = subprocess.run([stride, "pbcorrect"] + args, capture_output=True, text=True)
     assert r.returncode == 1
     assert msg in r.stderr and "Usage: StriDe PacBioSelfCorrection" in r.stderr
+
+
+@pytest.mark.parametrize("tool,args,msg", [
+    ("kmerfreq", [], "kmerfreq: no prefix"),
+    ("kmerfreq", ["-p", "x", "-c", "0"], "kmerfreq: invalid number of coverage: 0, must be greater than zero"),
+    ("kmercheck", ["-p", "x", "-o", "/tmp/lrsc_cli_t", "-b", "b.txt"], "kmercheck: missing arguments"),
+    ("kmercheck", ["-p", "x", "-o", "/tmp/lrsc_cli_t", "a.fa"], "kmercheck: no barcode"),
+    ("kmercheck", ["-p", "x", "-o", "/tmp/lrsc_cli_t", "-b", "b.txt", "-l", "8", "a.fa"], "invalid range of kmer size:8 - 35"),
+    ("kmercheck", ["-p", "x", "-o", "/tmp/lrsc_cli_t", "-b", "b.txt", "-s", "0", "a.fa"], "invalid step size: 0"),
+])
+def test_diagnostic_tools_validate_their_options_like_the_reference(stride, tool, args, msg):
+    # StriDe/kmerfreq.cpp:118-156, StriDe/kmercheck.cpp:128-225: message, usage, exit(EXIT_FAILURE)
+    r = subprocess.run([stride, tool] + args, capture_output=True, text=True)
+    assert r.returncode == 1
+    assert msg in r.stderr and "Usage: StriDe " + tool in (r.stderr + r.stdout)
 
 
 def test_unknown_command_fails(stride):
