@@ -6,6 +6,7 @@
 #include "extend_oracle.hpp"
 #include "dp_oracle.hpp"
 #include "process_oracle.hpp"
+#include "stdaln_oracle.hpp"
 #include "../include/lrsc.h"   // POD types only (lrsc_params, lrsc_biinterval); no product code is linked
 
 #include <cstring>
@@ -229,6 +230,14 @@ int orc_threshold_table_range(int cov, int end, float* out)
     KmerThreshold thr;
     thr.initialize(-1, end, cov);
     for(int m = 0; m < 3; ++m) for(int k = 0; k <= end + 1; ++k) out[m * (end + 2) + k] = thr.get(m, k);
+    return 0;
+}
+
+// ---- stdaln global alignment with the PacBio matrix (Thirdparty/stdaln.c) -> { '|' count, score, path_len }
+int orc_stdaln_global(const char* s1, const char* s2, int* out3)
+{
+    const StdalnGlobal r = stdaln_global_pacbio(s1, s2);
+    out3[0] = r.matches; out3[1] = r.score; out3[2] = r.path_len;
     return 0;
 }
 

@@ -208,6 +208,12 @@ class Oracle:
             raise RuntimeError("seed capacity too small")
         return count, seeds[:n].copy(), ratio
 
+    def stdaln_global(self, s1: str, s2: str):
+        """aln_stdaln(s1, s2, &aln_param_pacbio, GLOBAL, 1) -> ('|' count, score, path_len)."""
+        out = (C.c_int * 3)()
+        self.lib.orc_stdaln_global(s1.encode(), s2.encode(), out)
+        return int(out[0]), int(out[1]), int(out[2])
+
     def threshold_table_range(self, cov: int, end: int) -> np.ndarray:
         out = np.zeros((3, end + 2), dtype=np.float32)
         self.lib.orc_threshold_table_range(cov, end, _p(out))

@@ -13,6 +13,7 @@
 //   * Overlapper::extendMatch                   Thirdparty/overlapper.cpp:421-701
 //   * BCode::load / BCode::validate             PacBio/BCode.cpp:27-153 (--onlyseed, kmercheck)
 //   * KmerDistribution + compare()              Util/KmerDistribution.cpp:25-153 (kmercheck)
+//   * aln_stdaln global alignment, PacBio matrix Thirdparty/stdaln.c:364-546,780-862 (SAIPBSelfCTree's result choice)
 //
 // Everything above BWTAlgorithms.h (findInterval, LongReadProbe, FM-extend,
 // multiple_alignment) pulls Util/HashMap.h -> generated config.h + google
@@ -31,6 +32,7 @@
 #include "overlapper.h"
 #include "BCode.h"
 #include "KmerDistribution.h"
+#include "stdaln.h"
 
 extern "C" {
 
@@ -153,6 +155,19 @@ uint64_t ref_kd_compare(const int* crt, uint64_t n_crt, const int* err, uint64_t
     const std::string s = t.str() + v.str();
     if(out && cap >= s.size()) std::memcpy(out, s.data(), s.size());
     return s.size();
+}
+
+
+// ---- stdaln (Thirdparty/stdaln.c): aln_stdaln(s1, s2, &aln_param_pacbio, ALN_TYPE_GLOBAL, 1) as SAIPBSelfCTree.cpp:186-194 calls it
+// out3 = { number of '|' in outm, score, path_len }
+int ref_stdaln_global(const char* s1, const char* s2, int* out3)
+{
+    AlnAln* aln = aln_stdaln(s1, s2, &aln_param_pacbio, 1, 1);
+    int matches = 0;
+    for(int i = 0; aln->outm[i] != '\0'; i++) if(aln->outm[i] == '|') matches++;
+    out3[0] = matches; out3[1] = aln->score; out3[2] = aln->path_len;
+    aln_free_AlnAln(aln);
+    return 0;
 }
 
 } // extern "C"

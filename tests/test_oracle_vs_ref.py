@@ -42,3 +42,17 @@ def test_rank_and_char_match_reference(ref, oracle, small_ds, ext):
     pos = np.concatenate([np.arange(0, min(n, 5000)), rng.integers(0, n, size=100_000)]).astype(np.uint64)
     np.testing.assert_array_equal(rb.chars(pos), ob.chars(pos))
     rb.close(); ob.close()
+
+
+def test_stdaln_global_matches_reference_object_code(ref, oracle):
+    """aln_stdaln(s1, s2, &aln_param_pacbio, GLOBAL, 1) (SAIPBSelfCTree.cpp:186-194): '|' count, score and path length of the
+    restatement (oracle/stdaln_oracle.cpp) against Thirdparty/stdaln.c compiled in place, on fresh random pairs."""
+    import ctypes as C
+
+    from tests.golden.make_stdaln_kats import make_pairs
+
+    rng = np.random.default_rng(20261005)
+    for a, b in make_pairs(rng, 600):
+        out = (C.c_int * 3)()
+        ref.lib.ref_stdaln_global(a.encode(), b.encode(), out)
+        assert oracle.stdaln_global(a, b) == (out[0], out[1], out[2]), (len(a), len(b))
