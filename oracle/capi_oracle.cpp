@@ -7,6 +7,7 @@
 #include "dp_oracle.hpp"
 #include "process_oracle.hpp"
 #include "stdaln_oracle.hpp"
+#include "saipb_oracle.hpp"
 #include "../include/lrsc.h"   // POD types only (lrsc_params, lrsc_biinterval); no product code is linked
 
 #include <cstring>
@@ -239,6 +240,49 @@ int orc_stdaln_global(const char* s1, const char* s2, int* out3)
     const StdalnGlobal r = stdaln_global_pacbio(s1, s2);
     out3[0] = r.matches; out3[1] = r.score; out3[2] = r.path_len;
     return 0;
+}
+
+// ---- SAIPBSelfCorrectTree (row f3), driven the way its one -- commented-out -- call site drives it
+// (PacBioHybridCorrectionProcess.cpp:1083-1122): k-mers of three 17-mers of the source and of the reverse-complemented target are
+// collected by LF-walks, then mergeTwoSeedsUsingHash(last 17-mer of the source, target, extendKmerSize 15).  `source` must be at
+// least 51 characters.  Returns the FM-walk code (1, -1 .. -5); merged = source + pbseq.substr(17) when a path was found.
+// stats6 = { steps, maxUsedLeaves, results, hash entries, sourceFreq of the last addHash, targetFreq }
+int orc_saipb_merge(void* bwt, void* rbwt, const char* source_c, const char* between_c, const char* target_c, int dis, int max_leaves,
+                    char* out, uint64_t cap, int64_t* stats6)
+{
+    const std::string source(source_c), between(between_c), target(target_c);
+    if(source.size() < 51 || target.size() < 15) return -100;
+    const double maxRatio = 1.1, minRatio = 0.9;
+    const int minOffSet = 30;
+    const size_t extendKmerSize = 15, srcKmerSize = 17;
+    SaipbSelfCorrectTree tree(static_cast<RLBwt*>(bwt), static_cast<RLBwt*>(rbwt), between, 2);
+    std::string srcStr = source.substr(source.length() - srcKmerSize);
+    const size_t srcMaxLength = (size_t)(maxRatio * (dis + minOffSet) + srcStr.length() + extendKmerSize);
+    size_t sourceFreq = 0;
+    srcStr = source.substr(source.length() - srcKmerSize * 2, srcKmerSize);
+    sourceFreq = tree.addHashBySingleSeed(srcStr, srcKmerSize, extendKmerSize, srcMaxLength, true);
+    srcStr = source.substr(source.length() - srcKmerSize * 3, srcKmerSize);
+    sourceFreq = tree.addHashBySingleSeed(srcStr, srcKmerSize, extendKmerSize, srcMaxLength, true);
+    srcStr = source.substr(source.length() - (size_t)(srcKmerSize * 1.5), srcKmerSize);
+    sourceFreq = tree.addHashBySingleSeed(srcStr, srcKmerSize, extendKmerSize, srcMaxLength, true);
+    srcStr = source.substr(source.length() - srcKmerSize);
+    const std::string rvcTargetStr = reverse_complement(target);
+    const int targetMaxLength = (int)(maxRatio * (dis + minOffSet) + rvcTargetStr.length() + srcKmerSize);
+    size_t expectedLength = (size_t)dis + rvcTargetStr.length();
+    const size_t targetFreq = tree.addHashBySingleSeed(rvcTargetStr, srcKmerSize, extendKmerSize, (size_t)targetMaxLength, true, (int)expectedLength);
+    int srcMinLength = (int)(minRatio * (dis - minOffSet) + srcStr.length() + extendKmerSize);
+    if(srcMinLength < 0) srcMinLength = 0;
+    expectedLength = srcStr.length() + (size_t)dis + target.length();
+    std::string pbseq;
+    const int rc = tree.mergeTwoSeedsUsingHash(srcStr, target, pbseq, extendKmerSize, (size_t)max_leaves, (size_t)srcMinLength, srcMaxLength, expectedLength);
+    std::string merged;
+    if(!pbseq.empty()) merged = source + pbseq.substr(srcKmerSize);
+    if(out && cap > merged.size()) { std::memcpy(out, merged.data(), merged.size()); out[merged.size()] = 0; }
+    if(stats6) {
+        stats6[0] = (int64_t)tree.steps; stats6[1] = (int64_t)tree.maxUsedLeaves; stats6[2] = (int64_t)tree.numResults;
+        stats6[3] = (int64_t)tree.hashSize(); stats6[4] = (int64_t)sourceFreq; stats6[5] = (int64_t)targetFreq;
+    }
+    return rc;
 }
 
 // ---- IntervalTree (PacBio/IntervalTree.cpp) -----------------------------------------------------

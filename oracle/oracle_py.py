@@ -208,6 +208,17 @@ class Oracle:
             raise RuntimeError("seed capacity too small")
         return count, seeds[:n].copy(), ratio
 
+    def saipb_merge(self, bwt, rbwt, source: str, between: str, target: str, dis: int, max_leaves: int = 32):
+        """SAIPBSelfCorrectTree driven like its (commented-out) call site -> (code, merged, stats dict)."""
+        cap = len(source) + 3 * max(dis, 0) + len(target) + 4096
+        out = C.create_string_buffer(cap)
+        st = (C.c_int64 * 6)()
+        self.lib.orc_saipb_merge.restype = C.c_int
+        rc = self.lib.orc_saipb_merge(C.c_void_p(bwt.h), C.c_void_p(rbwt.h), source.encode(), between.encode(), target.encode(), C.c_int(dis),
+                                      C.c_int(max_leaves), out, C.c_uint64(cap), st)
+        keys = ("steps", "max_leaves", "results", "hash_entries", "source_freq", "target_freq")
+        return rc, out.value.decode(), dict(zip(keys, [int(x) for x in st]))
+
     def stdaln_global(self, s1: str, s2: str):
         """aln_stdaln(s1, s2, &aln_param_pacbio, GLOBAL, 1) -> ('|' count, score, path_len)."""
         out = (C.c_int * 3)()
