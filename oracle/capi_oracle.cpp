@@ -377,6 +377,7 @@ struct OrcRun {
     std::vector<int64_t> counters;     // per read: 10 counters (PacBioSelfCorrectionResult order) + merge flag
     std::vector<int32_t> walks;        // flat: read, srcStart, trgStart, code, via
     uint64_t walk_stats[3] = {0, 0, 0};
+    uint64_t spec[6] = {0, 0, 0, 0, 0, 0};
 };
 
 void* orc_correct_reads(void* bwt, void* rbwt, const lrsc_params* p, const char* bases, const uint64_t* off,
@@ -418,6 +419,7 @@ void* orc_correct_reads(void* bwt, void* rbwt, const lrsc_params* p, const char*
         run->walk_stats[0] += res.walk_stats.steps;
         run->walk_stats[1] += res.walk_stats.leaf_expansions;
         run->walk_stats[2] += res.walk_stats.refine_calls;
+        for(int i = 0; i < 6; ++i) run->spec[i] += res.spec[i];
     }
     run->correct_fa = post.correct_fa;
     run->discard_fa = post.discard_fa;
@@ -449,6 +451,12 @@ void orc_run_walk_stats(void* h, uint64_t* out3)
 {
     const OrcRun* r = static_cast<OrcRun*>(h);
     for(int i = 0; i < 3; ++i) out3[i] = r->walk_stats[i];
+}
+// source-k-mer prediction statistics of the run (process_oracle.hpp: CorrectionResult::spec)
+void orc_run_spec_stats(void* h, uint64_t* out6)
+{
+    const OrcRun* r = static_cast<OrcRun*>(h);
+    for(int i = 0; i < 6; ++i) out6[i] = r->spec[i];
 }
 
 } // extern "C"

@@ -317,6 +317,13 @@ class OracleRun:
         self.o.lib.orc_run_walk_stats(self.h, _p(out))
         return tuple(int(x) for x in out)  # steps, leaf expansions, refine calls
 
+    @property
+    def spec_stats(self):
+        out = np.zeros(6, dtype=np.uint64)
+        self.o.lib.orc_run_spec_stats.argtypes = [C.c_void_p, C.c_void_p]
+        self.o.lib.orc_run_spec_stats(self.h, _p(out))
+        return dict(zip(("walks", "hit", "miss_after_fm", "miss_after_dp", "miss_after_raw", "miss_k"), (int(x) for x in out)))
+
     def close(self):
         if self.h:
             self.o.lib.orc_run_free(self.h)

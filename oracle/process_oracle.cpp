@@ -50,6 +50,8 @@ void SelfCorrectionProcess::initCorrect(std::string& readSeq, const SeedFeature:
     pieceVec.push_back(seedVec[0]);
     pieceVec.back().seedStr.reserve(readSeq.length());
 
+    const SeedFeature* lastSeed = &seedVec[0];     // instrumentation only: the raw seed the source currently ends with
+    int lastVia = -1;                              // -1 first seed, 0 FM, 1 DP, 2 raw/split
     int case_number = 1;
     for(SeedFeature::SeedVector::const_iterator iterTarget = seedVec.begin() + 1; iterTarget != seedVec.end();
         iterTarget++, case_number++) {
@@ -57,6 +59,20 @@ void SelfCorrectionProcess::initCorrect(std::string& readSeq, const SeedFeature:
         SeedFeature& source = pieceVec.back();
         std::string mergedSeq;
         const int walkSrcStart = source.seedStartPos;
+        {   // instrumentation only (no effect on the result): predicted vs actual source k-mer of this walk
+            const SeedFeature& target = *iterTarget;
+            auto ksize = [&](int endBest, bool srcRepeat, int srcLen) {
+                int k = std::min(endBest, target.startBestKmerSize) - 2;
+                if(srcRepeat || target.isRepeat) { k = std::min(srcLen, target.seedLen); k = std::min(k, m_params.startKmerLen + 2); }
+                return k;
+            };
+            const int k_true = ksize(source.endBestKmerSize, source.isRepeat, source.seedLen);
+            const int k_pred = ksize(lastSeed->endBestKmerSize, lastSeed->isRepeat, lastSeed->seedLen);
+            result.spec[0]++;
+            if(k_true != k_pred || k_pred > lastSeed->seedLen || k_pred < 0) result.spec[5]++;
+            else if(source.seedStr.substr(source.seedLen - k_true) == lastSeed->seedStr.substr(lastSeed->seedLen - k_pred)) result.spec[1]++;
+            else result.spec[2 + (lastVia < 0 ? 2 : lastVia)]++;
+        }
 
         for(int next = 0; next < m_params.nextTarget && (iterTarget + next) != seedVec.end(); next++) {
             const SeedFeature& target = *(iterTarget + next);
@@ -68,6 +84,7 @@ void SelfCorrectionProcess::initCorrect(std::string& readSeq, const SeedFeature:
                 source.append(mergedSeq, target);
                 iterTarget += next;
                 case_number += next;
+                lastSeed = &*iterTarget; lastVia = 0;
                 break;
             }
         }
@@ -97,6 +114,7 @@ void SelfCorrectionProcess::initCorrect(std::string& readSeq, const SeedFeature:
                 }
                 result.correctedLen += target.seedStr.length();
             }
+            lastSeed = &target; lastVia = isMSAlignmentSuccess ? 1 : 2;
         }
     }
 }

@@ -46,6 +46,10 @@ struct CorrectionResult {            // PacBioSelfCorrectionProcess.h:58-94
     std::vector<WalkRecord> walks;   // not in the reference: test visibility
     SeedFeature::SeedVector seeds;   // not in the reference: test visibility
     WalkStats walk_stats;
+    // not in the reference: how often the source k-mer of a walk equals the tail of the previous TARGET seed's own string
+    // (what a walk-parallel schedule would assume before the previous walk has run).  [0] walks checked, [1] hits,
+    // misses by what the previous walk did: [2] FM success, [3] DP consensus, [4] raw copy / split, [5] k differs
+    uint64_t spec[6] = {0, 0, 0, 0, 0, 0};
 };
 
 class SelfCorrectionProcess {
