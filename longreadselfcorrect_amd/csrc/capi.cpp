@@ -25,6 +25,7 @@
 #include "correct_dev.h"
 #include "correct_layout.h"
 #include "dp_dev.h"
+#include "wp.h"
 #include "introsort_emul.h"
 
 using namespace lrsc;
@@ -1424,6 +1425,7 @@ struct CorrectScratch {
     DevBuf<FmIndexDev> d_fm;
     DevBuf<unsigned long long> d_prof;
     DpStage stage;
+    struct WpScratch* wp = nullptr;          // buffers of the walk-parallel flow
     hipStream_t ystream = nullptr;
     hipEvent_t y0 = nullptr, y1 = nullptr;
     ~CorrectScratch()
@@ -1433,7 +1435,384 @@ struct CorrectScratch {
         if(y1) (void)hipEventDestroy(y1);
     }
 };
-static void free_correct_scratch(CorrectScratch* cs) { delete cs; }
+struct WpScratch;
+static void free_wp_scratch(WpScratch* w);
+static void free_correct_scratch(CorrectScratch* cs) { if(cs) free_wp_scratch(cs->wp); delete cs; }
+
+// ---------------------------------------------------------------------------------------
+// the walk-parallel flow (wp.h / wp.hip): default implementation of lrsc_batch_correct
+// ---------------------------------------------------------------------------------------
+// Bump allocator over grow-only device chunks: results that later rounds still read (queries, result paths, DP consensus)
+// live here until the read range is done.  reset() keeps the chunks, so a loop over same-shaped batches stops allocating.
+struct DevArena {
+    std::vector<DevBuf<uint8_t>*> chunks;
+    size_t cur = 0, off = 0;
+    ~DevArena() { for(auto* c : chunks) delete c; }
+    void reset() { cur = 0; off = 0; }
+    hipError_t alloc(size_t bytes, uint8_t** out)
+    {
+        bytes = (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
+        while(cur < chunks.size()) {
+            if(chunks[cur]->cap - off >= bytes) { *out = chunks[cur]->p + off; off += bytes; return hipSuccess; }
+            // an empty chunk that is too small is replaced rather than skipped (grow-only, few chunks)
+            if(off == 0) { hipError_t e = chunks[cur]->reserve(bytes + bytes / 8); if(e != hipSuccess) return e; continue; }
+            ++cur; off = 0;
+        }
+        auto* c = new(std::nothrow) DevBuf<uint8_t>();
+        if(!c) return hipErrorOutOfMemory;
+        hipError_t e = c->reserve(std::max<size_t>(bytes + bytes / 8, 64u << 20));
+        if(e != hipSuccess) { delete c; return e; }
+        chunks.push_back(c);
+        cur = chunks.size() - 1;
+        *out = c->p; off = bytes;
+        return hipSuccess;
+    }
+};
+
+struct WpScratch {
+    DevBuf<WpReadWork> d_work;
+    DevBuf<WpRead> d_reads;
+    DevBuf<WpSlot> d_slots;
+    DevBuf<uint64_t> d_sz;                 // three arrays of (entries + 1)
+    DevBuf<uint32_t> d_key, d_key_tmp, d_list, d_list_tmp, d_small;   // d_small: plan_stats[4], queue, n_dp_items, n_req
+    DevBuf<WpDpItem> d_items;
+    DevBuf<WpRequest> d_req;
+    DevBuf<uint8_t> d_prep, d_lane;
+    DevArena persist;
+    void* cub_tmp = nullptr;
+    size_t cub_cap = 0;
+    ~WpScratch() { if(cub_tmp) (void)hipFree(cub_tmp); }
+};
+
+static void free_wp_scratch(WpScratch* w) { delete w; }
+
+static int batch_correct_wp(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result* res, uint64_t* piece_off, uint64_t piece_cap, char* out,
+                            uint64_t out_cap, uint64_t* n_pieces_out, uint64_t* out_used)
+{
+    const lrsc_params& p = ctx->params;
+    const uint32_t n = b->n_reads;
+    const bool wide = ctx->fm.wide != 0;
+    const uint32_t psz = wide ? 8 : 4;
+    const uint32_t lbytes = (uint32_t)leaf_bytes(wide);
+    const bool verbose = std::getenv("LRSC_CORRECT_PROFILE") != nullptr;
+
+    double freqs[101];
+    for(int i = 0; i <= 100; ++i) freqs[i] = 0;
+    for(int i = p.min_kmer_len; i <= 100; i++) freqs[i] = pow(1 - p.error_rate, i) * (size_t)p.pb_coverage;
+
+    if(!ctx->cs) ctx->cs = new(std::nothrow) CorrectScratch();
+    if(!ctx->cs) return fail(LRSC_ERR_NOMEM, "correct scratch");
+    CorrectScratch& cs = *ctx->cs;
+    if(!cs.wp) cs.wp = new(std::nothrow) WpScratch();
+    if(!cs.wp) return fail(LRSC_ERR_NOMEM, "correct scratch");
+    WpScratch& ws = *cs.wp;
+    HIP_TRY(cs.d_plan.reserve(n));
+    HIP_TRY(cs.d_freqs.reserve(101));
+    HIP_TRY(hipMemcpyAsync(cs.d_freqs.p, freqs, sizeof(freqs), hipMemcpyHostToDevice, ctx->stream));
+
+    // ---- per-read bounds (longest gap / query any walk of the read can have) -> output slots, skipped reads -----------
+    CorrectArgs pa{};
+    pa.codes = b->d_codes; pa.read_off = b->d_off; pa.seeds = b->d_seeds; pa.seed_count = b->d_seed_count;
+    pa.n_reads = n; pa.min_k = b->min_k; pa.next_target = p.next_target; pa.plan = cs.d_plan.p;
+    hipError_t e = launch_correct_plan(pa, ctx->stream);
+    if(e != hipSuccess) return hip_fail(e, "correct_plan");
+    std::vector<ReadPlan> plan(n);
+    std::vector<uint32_t> seed_count(n);
+    std::vector<uint64_t> off(n + 1);
+    HIP_TRY(hipMemcpyAsync(plan.data(), cs.d_plan.p, (size_t)n * sizeof(ReadPlan), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(seed_count.data(), b->d_seed_count, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(off.data(), b->d_off, (size_t)(n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+
+    std::vector<WpReadWork> work(n);
+    std::vector<int> skipped(n, 0);
+    uint64_t out_total = 0, piece_total = 0, n_slots = 0;
+    for(uint32_t r = 0; r < n; ++r) {
+        WpReadWork& w = work[r];
+        std::memset(&w, 0, sizeof(w));
+        const uint64_t rlen = off[r + 1] - off[r];
+        const uint32_t ns = seed_count[r];
+        w.out_off = out_total; w.piece_off = piece_total; w.slot_first = n_slots;
+        if(ns < 2) continue;                                          // nothing to correct: the read is discarded
+        // every walk appends at most maxLength + 1 + |target| - initk characters, walks <= seeds, gaps sum to <= |read|
+        // (a DP consensus can be longer than its query by the insertion columns it keeps: budget 2x the raw segment)
+        const uint64_t cap = rlen + (uint64_t)((p.no_dp ? 1.2 : 2.0) * (double)rlen) + (uint64_t)ns * (2 * kMaxInitK + 16 + (p.no_dp ? 0 : 128)) + 64;
+        if(cap >= (1ull << 32)) { skipped[r] = LRSC_READ_TOO_LONG; continue; }
+        if(plan[r].lq_max >= 65535) { skipped[r] = LRSC_READ_WALK_QUERY_TOO_LONG; continue; }
+        w.out_cap = (uint32_t)cap;
+        w.piece_cap = p.split ? ns : 1;
+        w.n_seeds = ns;
+        out_total += ((uint64_t)w.out_cap + 15) & ~15ull;
+        piece_total += w.piece_cap;
+        n_slots += ns - 1;
+    }
+    if(n_slots >= (1ull << 32)) return fail(LRSC_ERR_UNSUPPORTED, "batch: more than 2^32 seed pairs (split the input)");
+
+    HIP_TRY(ws.d_work.reserve(n));
+    HIP_TRY(ws.d_reads.reserve(n));
+    HIP_TRY(ws.d_slots.reserve(std::max<uint64_t>(n_slots, 1)));
+    HIP_TRY(ws.d_small.reserve(16));
+    HIP_TRY(ws.d_req.reserve(n));
+    HIP_TRY(cs.d_codes_out.reserve(std::max<uint64_t>(out_total, 64)));
+    HIP_TRY(cs.d_pieces.reserve(std::max<uint64_t>(piece_total, 1)));
+    HIP_TRY(hipMemcpyAsync(ws.d_work.p, work.data(), (size_t)n * sizeof(WpReadWork), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ws.d_reads.p, 0, (size_t)n * sizeof(WpRead), ctx->stream));
+
+    WpArgs a{};
+    a.codes = b->d_codes; a.read_off = b->d_off; a.seeds = b->d_seeds; a.seed_count = b->d_seed_count;
+    a.n_reads = n; a.min_k = b->min_k;
+    a.work = ws.d_work.p; a.reads = ws.d_reads.p; a.slots = ws.d_slots.p; a.n_slots = n_slots;
+    a.seed_size = (uint32_t)p.idmer_len; a.min_overlap = (uint32_t)p.min_kmer_len; a.max_leaves = (uint32_t)p.max_leaves;
+    a.start_kmer_len = p.start_kmer_len; a.next_target = p.next_target; a.split = p.split; a.no_dp = p.no_dp;
+    a.pb_coverage = (uint64_t)p.pb_coverage; a.pacbio_error_rate = p.error_rate;
+    a.freqs_of_kmer_size = cs.d_freqs.p;
+    a.psz = psz; a.lbytes = lbytes;
+    a.plan_stats = ws.d_small.p; a.queue = ws.d_small.p + 4; a.n_dp_items = ws.d_small.p + 5; a.n_req_out = ws.d_small.p + 6;
+    a.req_out = ws.d_req.p; a.req_cap = n;
+    a.out_codes = cs.d_codes_out.p; a.piece_start = cs.d_pieces.p;
+    a.auto_dp = (!p.no_dp && p.next_target == 1) ? 1u : 0u;
+    a.ctr = ctx->d_ctr;
+    if(b->debug_flags & LRSC_DEBUG_WALKS) {
+        if(!b->d_walk_log) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_walk_log), b->seed_cap));
+        HIP_TRY(hipMemsetAsync(b->d_walk_log, 0, b->seed_cap, ctx->stream));
+        a.walk_log = b->d_walk_log;
+        b->walk_log_done = false;
+    }
+
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    uint32_t max_lanes = (uint32_t)cus * 4u * 4u * 64u;              // 4 wavefronts per SIMD (128 VGPRs)
+    if(const char* ev = std::getenv("LRSC_WP_LANES")) max_lanes = (uint32_t)std::max(64, std::atoi(ev));
+    uint64_t prep_budget = 32ull << 30, lane_budget = 32ull << 30;
+    if(const char* ev = std::getenv("LRSC_WP_PREP_MB")) prep_budget = std::max<uint64_t>(1, (uint64_t)std::atoll(ev)) << 20;
+    if(const char* ev = std::getenv("LRSC_WP_LANE_MB")) lane_budget = std::max<uint64_t>(1, (uint64_t)std::atoll(ev)) << 20;
+
+    // One extension launch over list entries [first, first + count) whose result paths fit `pathw` words
+    auto extend_range = [&](WpArgs x, const uint32_t* list, const WpRequest* reqs, uint32_t count, uint32_t pathw) -> hipError_t {
+        if(count == 0) return hipSuccess;
+        const WpLaneLayout LL = wp_lane_layout(lbytes, pathw);
+        uint64_t lanes = std::min<uint64_t>(((uint64_t)count + 63) & ~63ull, max_lanes);
+        lanes = std::max<uint64_t>(64, std::min<uint64_t>(lanes, (lane_budget / LL.total) & ~63ull));
+        hipError_t e2 = ws.d_lane.reserve(lanes * LL.total);
+        if(e2 != hipSuccess) return e2;
+        x.list = list; x.reqs = reqs; x.n_list = count;
+        x.lane_ws = ws.d_lane.p; x.lane_ws_bytes = LL.total; x.lane_pathw = pathw; x.n_lanes = (uint32_t)lanes;
+        e2 = hipMemsetAsync(x.queue, 0, sizeof(uint32_t), ctx->stream);
+        if(e2 != hipSuccess) return e2;
+        return launch_wp_extend(ctx->fm, x, ctx->stream);
+    };
+
+    // ---- read ranges whose prepared tables fit the budget (about 40 bytes per query character + 6 KB per walk) -------------------
+    DpStage& stage = cs.stage;
+    std::vector<WpDpItem> items;
+    std::vector<DpRequest> reqs;
+    std::vector<WpRequest> hreq;
+    std::vector<uint32_t> hlist;
+    uint32_t r0 = 0;
+    uint64_t rounds_total = 0;
+    while(r0 < n) {
+        uint32_t r1 = r0;
+        uint64_t est = 0;
+        while(r1 < n) {
+            const uint64_t ns = work[r1].n_seeds;
+            const uint64_t need = ns >= 2 ? 48 * (off[r1 + 1] - off[r1] + 64 * ns) + ns * 8192 : 0;
+            if(r1 > r0 && est + need > prep_budget) break;
+            est += need;
+            ++r1;
+        }
+        const uint64_t slot_base = work[r0].slot_first;
+        const uint64_t slot_end = r1 < n ? work[r1].slot_first : n_slots;
+        const uint32_t n_range = (uint32_t)(slot_end - slot_base);
+        a.r0 = r0; a.r1 = r1; a.slot_base = slot_base;
+        ws.persist.reset();
+        if(n_range != 0)
+        for(uint32_t round = 0;; ++round) {
+            // entries of this round: every slot of the range (round 0) or what the stitch pass asked for
+            uint32_t n_ent = n_range;
+            a.list = nullptr; a.reqs = nullptr;
+            if(round != 0) {
+                uint32_t n_req = 0;
+                HIP_TRY(hipStreamSynchronize(ctx->stream));                      // ctx->stream is non-blocking: plain hipMemcpy does not wait for it
+                HIP_TRY(hipMemcpy(&n_req, a.n_req_out, sizeof(uint32_t), hipMemcpyDeviceToHost));
+                if(n_req == 0) break;
+                if(n_req > n) return fail(LRSC_ERR_LIMIT, "walk-parallel flow: request list overflow");
+                hreq.resize(n_req);
+                HIP_TRY(hipMemcpy(hreq.data(), ws.d_req.p, (size_t)n_req * sizeof(WpRequest), hipMemcpyDeviceToHost));
+                std::sort(hreq.begin(), hreq.end(), [](const WpRequest& x, const WpRequest& y) { return x.slot < y.slot; });
+                hlist.resize(n_req);
+                for(uint32_t i = 0; i < n_req; ++i) hlist[i] = hreq[i].slot;
+                n_ent = n_req;
+            }
+            HIP_TRY(ws.d_sz.reserve(3 * ((size_t)n_ent + 1)));
+            HIP_TRY(ws.d_key.reserve(n_ent));
+            HIP_TRY(ws.d_key_tmp.reserve(n_ent));
+            HIP_TRY(ws.d_list.reserve(n_ent));
+            HIP_TRY(ws.d_list_tmp.reserve(n_ent));
+            HIP_TRY(ws.d_items.reserve(n_ent));
+            a.sz_q = ws.d_sz.p; a.sz_prep = ws.d_sz.p + (n_ent + 1); a.sz_path = ws.d_sz.p + 2 * ((size_t)n_ent + 1);
+            a.sort_key = ws.d_key.p;
+            a.n_list = n_ent;
+            a.dp_items = ws.d_items.p; a.dp_items_cap = n_ent;
+            HIP_TRY(hipMemsetAsync(ws.d_sz.p, 0, 3 * ((size_t)n_ent + 1) * sizeof(uint64_t), ctx->stream));
+            HIP_TRY(hipMemsetAsync(ws.d_small.p, 0, 16 * sizeof(uint32_t), ctx->stream));
+            WpRequest* d_reqs_in = nullptr;
+            if(round != 0) {
+                // the request records move to the front half of a second buffer so that the stitch pass can write new ones
+                HIP_TRY(ws.d_list_tmp.reserve(std::max<size_t>(n_ent, 2 * (size_t)n_ent)));
+                d_reqs_in = reinterpret_cast<WpRequest*>(ws.d_list_tmp.p);
+                HIP_TRY(hipMemcpyAsync(d_reqs_in, hreq.data(), (size_t)n_ent * sizeof(WpRequest), hipMemcpyHostToDevice, ctx->stream));
+                HIP_TRY(hipMemcpyAsync(ws.d_list.p, hlist.data(), (size_t)n_ent * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+                a.list = ws.d_list.p; a.reqs = d_reqs_in;
+            }
+            e = launch_wp_plan(a, ctx->stream);
+            if(e != hipSuccess) return hip_fail(e, "wp_plan");
+            for(int j = 0; j < 3; ++j) {
+                e = wp_scan(ws.d_sz.p + (size_t)j * (n_ent + 1), (uint64_t)n_ent + 1, &ws.cub_tmp, &ws.cub_cap, ctx->stream);
+                if(e != hipSuccess) return hip_fail(e, "wp_scan");
+            }
+            uint64_t tot[3];
+            uint32_t stats[4];
+            for(int j = 0; j < 3; ++j)
+                HIP_TRY(hipMemcpyAsync(&tot[j], ws.d_sz.p + (size_t)j * (n_ent + 1) + n_ent, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(stats, ws.d_small.p, sizeof(stats), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            HIP_TRY(ws.persist.alloc(tot[0] + 64, &a.arena_q));
+            HIP_TRY(ws.persist.alloc(tot[2] + 64, &a.arena_path));
+            HIP_TRY(ws.d_prep.reserve(tot[1] + 64));
+            a.arena_prep = ws.d_prep.p;
+            e = launch_wp_materialize(a, ctx->stream);
+            if(e != hipSuccess) return hip_fail(e, "wp_materialize");
+
+            // launch order of round 0: long walks first (the few walks across long gaps need bigger path slots: own launches)
+            const uint32_t* ext_list = a.list;
+            uint32_t n_big = 0, n_mid = 0;
+            if(round == 0) {
+                // list_tmp = slot_base + i
+                hlist.resize(n_ent);
+                for(uint32_t i = 0; i < n_ent; ++i) hlist[i] = (uint32_t)slot_base + i;
+                HIP_TRY(hipMemcpyAsync(ws.d_list_tmp.p, hlist.data(), (size_t)n_ent * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+                e = wp_sort_list(ws.d_key.p, ws.d_key_tmp.p, ws.d_list.p, ws.d_list_tmp.p, n_ent, &ws.cub_tmp, &ws.cub_cap, ctx->stream);
+                if(e != hipSuccess) return hip_fail(e, "wp_sort_list");
+                ext_list = ws.d_list.p;
+                n_mid = stats[0]; n_big = stats[1];
+            }
+            const int st = timed_launch(ctx, LRSC_K_EXTEND, [&]() -> hipError_t {
+                hipError_t e2 = launch_wp_prepare(ctx->fm, a, ctx->stream);
+                if(e2 == hipSuccess) e2 = launch_wp_begin(ctx->fm, a, ctx->stream);
+                if(e2 != hipSuccess) return e2;
+                if(round == 0) {
+                    e2 = extend_range(a, ext_list, nullptr, n_big, stats[2]);
+                    if(e2 == hipSuccess) e2 = extend_range(a, ext_list + n_big, nullptr, n_mid - n_big, std::min(stats[2], kWpPathwMid));
+                    if(e2 == hipSuccess) e2 = extend_range(a, ext_list + n_mid, nullptr, n_ent - n_mid, std::min(stats[2], kWpPathwSmall));
+                    return e2;
+                }
+                return extend_range(a, a.list, a.reqs, n_ent, std::max(stats[2], 1u));
+            });
+            if(st != LRSC_OK) return st;
+
+            // ---- the DP stage for every failed walk of this round (and the explicit requests) ---------------------------------
+            uint32_t n_items = 0;
+            HIP_TRY(hipMemcpy(&n_items, a.n_dp_items, sizeof(uint32_t), hipMemcpyDeviceToHost));
+            if(n_items > n_ent) return fail(LRSC_ERR_LIMIT, "walk-parallel flow: DP item list overflow");
+            if(n_items != 0) {
+                items.resize(n_items);
+                HIP_TRY(hipMemcpy(items.data(), ws.d_items.p, (size_t)n_items * sizeof(WpDpItem), hipMemcpyDeviceToHost));
+                std::sort(items.begin(), items.end(), [](const WpDpItem& x, const WpDpItem& y) { return x.slot < y.slot; });
+                reqs.clear();
+                reqs.reserve(n_items);
+                for(const WpDpItem& it : items) {
+                    DpRequest q;
+                    std::memset(&q, 0, sizeof(q));
+                    q.q_off = it.q;                                                          // absolute device address (base pointer 0)
+                    q.lq = it.lq; q.k = it.k;
+                    q.coverage = (uint32_t)p.pb_coverage;
+                    q.min_overlap = it.lq / 10;                                              // path.length() / 10
+                    // identity / min_call_coverage from the two seeds' maxFixedMerFreq (:225-229)
+                    const size_t total = (size_t)it.total_freq;
+                    double identity = 0.65;
+                    size_t min_call_coverage = 15;
+                    identity += (total > 50 ? 0.05 : 0);
+                    identity += (total > 100 ? 0.05 : 0);
+                    min_call_coverage = total > 50 ? total * 0.4 : min_call_coverage;
+                    q.min_identity = identity; q.min_call_coverage = (int32_t)min_call_coverage;
+                    reqs.push_back(q);
+                }
+                const int sd = stage.run(ctx, nullptr, reqs);
+                if(sd != LRSC_OK) return sd;
+                uint8_t* cons_keep = nullptr;
+                HIP_TRY(ws.persist.alloc(stage.cons_total + 64, &cons_keep));
+                HIP_TRY(hipMemcpyAsync(cons_keep, stage.d_cons.p, stage.cons_total, hipMemcpyDeviceToDevice, ctx->stream));
+                HIP_TRY(hipMemcpyAsync(ws.d_items.p, items.data(), (size_t)n_items * sizeof(WpDpItem), hipMemcpyHostToDevice, ctx->stream));
+                a.dp_reqs = stage.d_reqs.p; a.dp_msa = stage.d_msa.p; a.dp_cons = cons_keep; a.n_dp = n_items;
+                e = launch_wp_dp_collect(a, ws.d_items.p, ctx->stream);
+                if(e != hipSuccess) return hip_fail(e, "wp_dp_collect");
+            }
+            HIP_TRY(hipMemsetAsync(a.n_req_out, 0, sizeof(uint32_t), ctx->stream));
+            e = launch_wp_stitch(a, ctx->stream);
+            if(e != hipSuccess) return hip_fail(e, "wp_stitch");
+            ++rounds_total;
+            if(verbose)
+                std::fprintf(stderr, "[lrsc] wp reads [%u, %u) round %u: %u entries, %u DP requests (%llu strings), arenas q %.1f MB prep %.1f MB path %.1f MB\n",
+                             r0, r1, round, n_ent, n_items, (unsigned long long)stage.n_strings, tot[0] / 1048576.0, tot[1] / 1048576.0, tot[2] / 1048576.0);
+            if(round > 100000) return fail(LRSC_ERR_LIMIT, "walk-parallel flow: too many rounds");
+        }
+        r0 = r1;
+    }
+    (void)rounds_total;
+    if(a.walk_log) b->walk_log_done = true;
+
+    // ---- results ---------------------------------------------------------------------------------------------------------------------
+    std::vector<WpRead> ro(n);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(ro.data(), ws.d_reads.p, (size_t)n * sizeof(WpRead), hipMemcpyDeviceToHost));
+    std::vector<uint32_t> pieces(std::max<uint64_t>(piece_total, 1));
+    if(piece_total) HIP_TRY(hipMemcpy(pieces.data(), cs.d_pieces.p, (size_t)piece_total * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    std::vector<uint64_t> dst_off(n + 1, 0);
+    uint64_t n_pieces = 0;
+    for(uint32_t r = 0; r < n; ++r) {
+        const WpRead& o = ro[r];
+        int status = skipped[r];
+        if(o.error == LRSC_WALK_ERR_GEOMETRY) status = LRSC_READ_GEOMETRY;
+        else if(o.error == LRSC_WALK_ERR_CODE) status = LRSC_READ_INTERNAL;
+        else if(o.error == LRSC_WALK_ERR_DP) status = LRSC_READ_DP_LIMIT;
+        else if(o.error == LRSC_WALK_ERR_OUTPUT) status = LRSC_READ_OUTPUT_LIMIT;
+        else if(o.error != 0) status = LRSC_READ_FRONTIER_LIMIT;
+        lrsc_read_result& R = res[r];
+        if(status != LRSC_READ_OK) {
+            // this read alone could not be corrected: it comes back as "not merged" (-> discard.fa) with its status
+            std::memset(&R, 0, sizeof(R));
+            R.piece_first = n_pieces;
+            R.status = status;
+            dst_off[r + 1] = dst_off[r];
+            continue;
+        }
+        R.merge = (int32_t)o.merge; R.n_pieces = o.n_pieces; R.piece_first = n_pieces;
+        R.total_reads_len = (int64_t)(off[r + 1] - off[r]); R.corrected_len = o.c[1]; R.total_seed_num = seed_count[r]; R.total_walk_num = o.c[3];
+        R.high_error_num = o.c[4]; R.exceed_depth_num = o.c[5]; R.exceed_leave_num = o.c[6]; R.fm_num = o.c[7];
+        R.dp_num = o.c[8]; R.seed_dis = o.c[9];
+        R.status = LRSC_READ_OK; R.pad = 0;
+        dst_off[r + 1] = dst_off[r] + o.out_len;
+        for(uint32_t j = 0; j < o.n_pieces; ++j) {
+            if(piece_off && n_pieces < piece_cap) piece_off[n_pieces] = dst_off[r] + pieces[work[r].piece_off + j];
+            ++n_pieces;
+        }
+    }
+    const uint64_t used = dst_off[n];
+    if(piece_off && n_pieces < piece_cap) piece_off[n_pieces] = used;
+    *n_pieces_out = n_pieces;
+    *out_used = used;
+    if(!out || !piece_off || used > out_cap || n_pieces + 1 > piece_cap) return fail(LRSC_ERR_CAPACITY, "output buffers too small");
+    if(used) {
+        HIP_TRY(cs.d_dst_off.reserve(n + 1));
+        HIP_TRY(cs.d_dst.reserve(used));
+        HIP_TRY(hipMemcpyAsync(cs.d_dst_off.p, dst_off.data(), (size_t)(n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+        e = launch_wp_gather(a, cs.d_dst_off.p, cs.d_dst.p, ctx->stream);
+        if(e != hipSuccess) return hip_fail(e, "wp_gather");
+        HIP_TRY(hipMemcpyAsync(out, cs.d_dst.p, used, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return LRSC_OK;
+}
 
 // ---------------------------------------------------------------------------------------
 // the whole per-read path on the device
@@ -1457,6 +1836,11 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
     if(!b->seeds_done) {
         const int st = lrsc_batch_find_seeds(ctx, b);
         if(st != LRSC_OK) return st;
+    }
+    {
+        // default: the walk-parallel flow (wp.hip).  LRSC_CORRECT_FLOW=chain keeps the lane-per-read chain kernel of rounds 1-2.
+        const char* flow = std::getenv("LRSC_CORRECT_FLOW");
+        if(!(flow && std::strcmp(flow, "chain") == 0)) return batch_correct_wp(ctx, b, res, piece_off, piece_cap, out, out_cap, n_pieces_out, out_used);
     }
     const bool wide = ctx->fm.wide != 0;
     const size_t psz = wide ? 8 : 4;

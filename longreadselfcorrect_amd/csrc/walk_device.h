@@ -615,9 +615,10 @@ struct Walk {
     bool ended;                        // the frontier overflowed maxLeaves: the loop ends after this isTerminated
     bool profile = false;              // per-step tick counters on (LRSC_CORRECT_PROFILE)
 
-    __device__ __noinline__ void begin()
+    // The constructor's per-walk tables that stay fixed during the walk (.cpp:90-94,127-152 after the bulk look-ups of
+    // prepare_offset): the interval "trees" as sorted k-mer chains, the 5-mer chains, the isTerminated filter.
+    __device__ __noinline__ void begin_static()
     {
-        const uint64_t t_run0 = __builtin_readcyclecounter();
         // --- interval "trees": compact the valid 9-mer entries (emplace_back order), introsort, chain by k-mer ---
         auto build9 = [&](SortItem* it, uint32_t n_all, uint16_t* head, uint16_t* next) -> uint32_t {
             uint32_t n = 0;
@@ -662,13 +663,18 @@ struct Walk {
                 if(h < 64) tmask0 |= 1ull << h; else tmask1 |= 1ull << (h - 64);
             }
         }
+    }
 
-        // --- root (initialRootNode, .cpp:108-124; leafInfo ctor, .h:156-171) ---
+    // --- root (initialRootNode, .cpp:108-124; leafInfo ctor, .h:156-171).  root_iv: the root k-mer's bi-interval {fwd.lo,
+    //     fwd.hi, rvc.lo, rvc.hi} when a preparation pass has already searched it, nullptr to search it here ---
+    __device__ __noinline__ void begin_root(const P* root_iv)
+    {
         ring_free = 0xFFFFFFFEu; path_free = 0xFFFFFFFEu;
         Leaf<P>& root = cur[0];
         root.suf_lo = 0; root.suf_hi = 0;
         for(uint32_t t = 0; t < initk; ++t) suf_push(root, q[t]);
-        find_suffix(root, initk);
+        if(root_iv) { root.flo = root_iv[0]; root.fhi = root_iv[1]; root.rlo = root_iv[2]; root.rhi = root_iv[3]; }
+        else find_suffix(root, initk);
         root.lastOverlapLen = root.currOverlapLen = root.queryOverlapLen = initk;
         currentLength = currentKmerSize = initk;
         root.lastSeedIdx = (uint64_t)initk - seedSize;
@@ -688,6 +694,13 @@ struct Walk {
         for(uint32_t t = 0; t < initk; ++t) path_set(paths, t, q[t]);
         n_cur = 1; n_nxt = 0; n_results = 0;
         ended = false;
+    }
+
+    __device__ __noinline__ void begin()
+    {
+        const uint64_t t_run0 = __builtin_readcyclecounter();
+        begin_static();
+        begin_root(nullptr);
         cyc_setup += __builtin_readcyclecounter() - t_run0;
     }
 
