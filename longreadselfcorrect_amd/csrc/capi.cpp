@@ -56,6 +56,7 @@ static int hip_fail(hipError_t e, const char* what)
 struct DeviceCopy {
     void* blocks[2] = {nullptr, nullptr};
     uint64_t* dollars[2] = {nullptr, nullptr};
+    uint32_t* dollar_dir[2] = {nullptr, nullptr};
     void* ktab[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     FmIndexDev dev{};
 };
@@ -259,7 +260,7 @@ extern "C" int lrsc_index_info_get(const lrsc_index* idx, lrsc_index_info* out)
     for(int s = 0; s < 2; ++s) {
         out->num_runs[s] = idx->image[s].n_runs;
         for(int c = 0; c < 5; ++c) out->pred_count[s][c] = idx->image[s].pred[c];
-        out->device_bytes += idx->image[s].blocks.size() + idx->image[s].dollars.size() * 8;
+        out->device_bytes += idx->image[s].blocks.size() + idx->image[s].dollars.size() * 8 + idx->image[s].dollar_dir.size() * 4;
     }
     out->block_bytes = 64;
     out->block_symbols = idx->wide ? Block64::kSyms : Block32::kSyms;
@@ -282,9 +283,13 @@ extern "C" int lrsc_index_upload(lrsc_index* idx, int device)
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dc.dollars[s]), db));
         if(!im.dollars.empty())
             HIP_TRY(hipMemcpy(dc.dollars[s], im.dollars.data(), im.dollars.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dc.dollar_dir[s]), im.dollar_dir.size() * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpy(dc.dollar_dir[s], im.dollar_dir.data(), im.dollar_dir.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         FmStrand& fs = dc.dev.strand[s];
         fs.blocks = dc.blocks[s];
         fs.dollars = dc.dollars[s];
+        fs.dollar_dir = dc.dollar_dir[s];
+        fs.dollar_group_syms = (uint64_t)(idx->wide ? Block64::kSyms : Block32::kSyms) << kDollarDirShift;
         fs.n_dollars = im.dollars.size();
         fs.n_symbols = im.n_symbols;
         fs.n_blocks = im.n_blocks;
@@ -341,6 +346,7 @@ extern "C" void lrsc_index_close(lrsc_index* idx)
         for(int s = 0; s < 2; ++s) {
             if(kv.second.blocks[s]) (void)hipFree(kv.second.blocks[s]);
             if(kv.second.dollars[s]) (void)hipFree(kv.second.dollars[s]);
+            if(kv.second.dollar_dir[s]) (void)hipFree(kv.second.dollar_dir[s]);
         }
         for(int t = 0; t < 5; ++t) if(kv.second.ktab[t]) (void)hipFree(kv.second.ktab[t]);
     }

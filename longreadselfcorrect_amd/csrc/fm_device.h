@@ -51,6 +51,9 @@ struct alignas(64) Block64 {
 static_assert(sizeof(Block32) == 64, "Block32 must be one 64-byte line");
 static_assert(sizeof(Block64) == 64, "Block64 must be one 64-byte line");
 
+// '$' directory granularity: one entry per 8 rank blocks (a '$' look-up is one directory entry + the one or two list
+// entries of that group instead of a binary search over the whole list: 2 x log2(#reads) dependent loads)
+constexpr uint32_t kDollarDirShift = 3;
 constexpr uint32_t kFlag32 = 0x80000000u;
 constexpr uint64_t kFlag64 = 0x8000000000000000ull;
 
@@ -58,7 +61,9 @@ constexpr uint64_t kFlag64 = 0x8000000000000000ull;
 struct FmStrand {
     const void* blocks;          // Block32[] or Block64[]
     const uint64_t* dollars;     // sorted BWT positions holding '$'
+    const uint32_t* dollar_dir;  // dollar_dir[g] = number of '$' rows before block (g << kDollarDirShift): where a block's '$' rows start
     uint64_t n_dollars;
+    uint64_t dollar_group_syms;  // symbols per directory group (block symbols << kDollarDirShift)
     uint64_t n_symbols;
     uint64_t n_blocks;
     uint64_t pred[5];            // C[$ACGT]

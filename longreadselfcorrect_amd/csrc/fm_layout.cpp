@@ -100,6 +100,18 @@ static int build_image_t(const uint8_t* units, uint64_t n_units, uint64_t num_sy
         const uint64_t b = n_blocks - 1;
         for(int c = 0; c < 4; ++c) blk[b].cnt[c] = (CountT)counts[c];
     }
+    // '$' directory: rows before each group of blocks
+    {
+        const uint64_t n_groups = (n_blocks >> kDollarDirShift) + 2;
+        if(out.dollars.size() >= (1ull << 32)) { err = "more than 2^32 reads"; return LRSC_ERR_UNSUPPORTED; }
+        out.dollar_dir.assign(n_groups, 0);
+        size_t j = 0;
+        for(uint64_t g = 0; g < n_groups; ++g) {
+            const uint64_t start = (g << kDollarDirShift) * kSyms;
+            while(j < out.dollars.size() && out.dollars[j] < start) ++j;
+            out.dollar_dir[g] = (uint32_t)j;
+        }
+    }
     out.pred[0] = 0;
     out.pred[1] = n_dollar;
     out.pred[2] = out.pred[1] + counts[0];

@@ -11,6 +11,7 @@ namespace lrsc {
 struct StrandImage {
     std::vector<uint8_t> blocks;      // n_blocks * 64 bytes (Block32 or Block64)
     std::vector<uint64_t> dollars;    // sorted positions of '$' rows
+    std::vector<uint32_t> dollar_dir; // '$' rows before every group of 2^kDollarDirShift blocks (+ one terminal entry)
     uint64_t n_blocks = 0;
     uint64_t n_symbols = 0;
     uint64_t n_runs = 0;

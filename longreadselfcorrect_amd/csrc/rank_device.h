@@ -161,14 +161,17 @@ template <class P>
 struct StrandC {
     const void* blocks;
     const uint64_t* dollars;
+    const uint32_t* dollar_dir;
     uint64_t n_dollars;
+    uint32_t syms_per_group;  // symbols of one '$'-directory group
     P c1, c2, c3, c4, n;      // C[A], C[C], C[G], C[T], N
 };
 template <class P>
 __host__ __device__ __forceinline__ StrandC<P> strand_consts(const FmStrand& s)
 {
     StrandC<P> c;
-    c.blocks = s.blocks; c.dollars = s.dollars; c.n_dollars = s.n_dollars;
+    c.blocks = s.blocks; c.dollars = s.dollars; c.dollar_dir = s.dollar_dir; c.n_dollars = s.n_dollars;
+    c.syms_per_group = (uint32_t)s.dollar_group_syms;
     c.c1 = (P)s.pred[1]; c.c2 = (P)s.pred[2]; c.c3 = (P)s.pred[3]; c.c4 = (P)s.pred[4]; c.n = (P)s.n_symbols;
     return c;
 }
@@ -192,15 +195,19 @@ __host__ __device__ __forceinline__ P pred_next(const StrandC<P>& s, uint32_t co
     v += code >= 3 ? (s.n - s.c4) : 0;
     return v;
 }
+// '$' rows in [lo, hi), lo and hi inside one rank block: the directory entry of the block's group gives the first list entry that
+// can matter; a group holds a fraction of a '$' on average (one per read in >= 1024 symbols), so the scan is one or two entries
 template <class P>
 __host__ __device__ __forceinline__ uint64_t dollars_in_c(const StrandC<P>& s, uint64_t lo, uint64_t hi)
 {
-    uint64_t a = 0, b = s.n_dollars;
-    while(a < b) { const uint64_t m = (a + b) >> 1; if(s.dollars[m] < lo) a = m + 1; else b = m; }
-    const uint64_t first = a;
-    b = s.n_dollars;
-    while(a < b) { const uint64_t m = (a + b) >> 1; if(s.dollars[m] < hi) a = m + 1; else b = m; }
-    return a - first;
+    uint64_t j = s.dollar_dir[lo / s.syms_per_group];
+    uint64_t n = 0;
+    for(; j < s.n_dollars; ++j) {
+        const uint64_t d = s.dollars[j];
+        if(d >= hi) break;
+        n += d >= lo ? 1u : 0u;
+    }
+    return n;
 }
 
 // Occ over the first p symbols (p = idx + 1, 0 <= p <= N): RLBWT::getOcc (RLBWT.h:121-140)

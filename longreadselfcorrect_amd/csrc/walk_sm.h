@@ -191,6 +191,8 @@ __host__ __device__ __forceinline__ void sm_answer(const FmIndexDev& fm, const S
         SA.blocks = swap ? sR.blocks : sF.blocks;   SB.blocks = swap ? sF.blocks : sR.blocks;
         SA.dollars = swap ? sR.dollars : sF.dollars; SB.dollars = swap ? sF.dollars : sR.dollars;
         SA.n_dollars = swap ? sR.n_dollars : sF.n_dollars; SB.n_dollars = swap ? sF.n_dollars : sR.n_dollars;
+        SA.dollar_dir = swap ? sR.dollar_dir : sF.dollar_dir; SB.dollar_dir = swap ? sF.dollar_dir : sR.dollar_dir;
+        SA.syms_per_group = sF.syms_per_group; SB.syms_per_group = sF.syms_per_group;
         SA.c1 = swap ? sR.c1 : sF.c1; SA.c2 = swap ? sR.c2 : sF.c2; SA.c3 = swap ? sR.c3 : sF.c3; SA.c4 = swap ? sR.c4 : sF.c4; SA.n = swap ? sR.n : sF.n;
         SB.c1 = swap ? sF.c1 : sR.c1; SB.c2 = swap ? sF.c2 : sR.c2; SB.c3 = swap ? sF.c3 : sR.c3; SB.c4 = swap ? sF.c4 : sR.c4; SB.n = swap ? sF.n : sR.n;
         // a side that is not asked for searches the empty interval [0, -1] of block 0 and its answer is dropped: no branch,

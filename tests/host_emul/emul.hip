@@ -88,6 +88,8 @@ extern "C" void* emul_index_create(const uint8_t* bwt_units, uint64_t n0, const 
         FmStrand& fs = ix->dev.strand[s];
         fs.blocks = ix->image[s].blocks.data();
         fs.dollars = ix->image[s].dollars.data();
+        fs.dollar_dir = ix->image[s].dollar_dir.data();
+        fs.dollar_group_syms = (uint64_t)(ix->wide ? Block64::kSyms : Block32::kSyms) << kDollarDirShift;
         fs.n_dollars = ix->image[s].dollars.size();
         fs.n_symbols = ix->image[s].n_symbols;
         fs.n_blocks = ix->image[s].n_blocks;
