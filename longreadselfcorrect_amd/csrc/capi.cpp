@@ -1483,11 +1483,24 @@ struct WpScratch {
     DevBuf<uint32_t> d_key, d_key_tmp, d_list, d_list_tmp, d_small;   // d_small: plan_stats[4], queue, n_dp_items, n_req
     DevBuf<WpDpItem> d_items;
     DevBuf<WpRequest> d_req;
-    DevBuf<uint8_t> d_prep, d_lane;
+    DevBuf<uint8_t> d_prep, d_lane, d_lane_side, d_ctx[2];
+    hipStream_t side[2] = {nullptr, nullptr};
+    hipEvent_t ev_side[2] = {nullptr, nullptr}, ev_ready = nullptr;
+    DevBuf<unsigned long long> d_prof;
+    DevBuf<WpSched> d_sched;
+    DevBuf<uint32_t> d_sched_lists[2];
     DevArena persist;
     void* cub_tmp = nullptr;
     size_t cub_cap = 0;
-    ~WpScratch() { if(cub_tmp) (void)hipFree(cub_tmp); }
+    ~WpScratch()
+    {
+        if(cub_tmp) (void)hipFree(cub_tmp);
+        for(int i = 0; i < 2; ++i) {
+            if(side[i]) { (void)hipStreamSynchronize(side[i]); (void)hipStreamDestroy(side[i]); }
+            if(ev_side[i]) (void)hipEventDestroy(ev_side[i]);
+        }
+        if(ev_ready) (void)hipEventDestroy(ev_ready);
+    }
 };
 
 static void free_wp_scratch(WpScratch* w) { delete w; }
@@ -1585,6 +1598,11 @@ static int batch_correct_wp(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result* res,
         b->walk_log_done = false;
     }
 
+    if(verbose) {
+        HIP_TRY(ws.d_prof.reserve(16));
+        HIP_TRY(hipMemsetAsync(ws.d_prof.p, 0, 16 * sizeof(unsigned long long), ctx->stream));
+        a.prof = ws.d_prof.p;
+    }
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
     uint32_t max_lanes = (uint32_t)cus * 4u * 4u * 64u;              // 4 wavefronts per SIMD (128 VGPRs)
@@ -1593,19 +1611,109 @@ static int batch_correct_wp(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result* res,
     if(const char* ev = std::getenv("LRSC_WP_PREP_MB")) prep_budget = std::max<uint64_t>(1, (uint64_t)std::atoll(ev)) << 20;
     if(const char* ev = std::getenv("LRSC_WP_LANE_MB")) lane_budget = std::max<uint64_t>(1, (uint64_t)std::atoll(ev)) << 20;
 
-    // One extension launch over list entries [first, first + count) whose result paths fit `pathw` words
-    auto extend_range = [&](WpArgs x, const uint32_t* list, const WpRequest* reqs, uint32_t count, uint32_t pathw) -> hipError_t {
+    // side streams: the few walks across long gaps and the mid-size class run beside the bulk instead of before it (each is
+    // latency-bound on its own: a walk is a chain of dependent steps)
+    for(int i = 0; i < 2; ++i) {
+        if(!ws.side[i]) HIP_TRY(hipStreamCreateWithFlags(&ws.side[i], hipStreamNonBlocking));
+        if(!ws.ev_side[i]) HIP_TRY(hipEventCreateWithFlags(&ws.ev_side[i], hipEventDisableTiming));
+    }
+    if(!ws.ev_ready) HIP_TRY(hipEventCreateWithFlags(&ws.ev_ready, hipEventDisableTiming));
+
+    // One launch of the one-kernel form (wp_extend_kernel: every lane runs both kinds of step) over `count` list entries;
+    // stride 64 = one walk per wavefront
+    auto extend_range = [&](WpArgs x, const uint32_t* list, const WpRequest* reqs, uint32_t count, uint32_t pathw, hipStream_t st, int which, uint32_t stride) -> hipError_t {
         if(count == 0) return hipSuccess;
         const WpLaneLayout LL = wp_lane_layout(lbytes, pathw);
-        uint64_t lanes = std::min<uint64_t>(((uint64_t)count + 63) & ~63ull, max_lanes);
-        lanes = std::max<uint64_t>(64, std::min<uint64_t>(lanes, (lane_budget / LL.total) & ~63ull));
-        hipError_t e2 = ws.d_lane.reserve(lanes * LL.total);
+        uint64_t lanes = std::min<uint64_t>(stride == 1 ? (((uint64_t)count + 63) & ~63ull) : count, max_lanes / stride);
+        lanes = std::max<uint64_t>(1, std::min<uint64_t>(lanes, (lane_budget / (which ? 4 : 1)) / LL.total));
+        if(stride == 1) lanes = std::max<uint64_t>(64, lanes & ~63ull);
+        DevBuf<uint8_t>& buf = which ? ws.d_lane_side : ws.d_lane;
+        hipError_t e2 = buf.reserve(lanes * LL.total);
         if(e2 != hipSuccess) return e2;
         x.list = list; x.reqs = reqs; x.n_list = count;
-        x.lane_ws = ws.d_lane.p; x.lane_ws_bytes = LL.total; x.lane_pathw = pathw; x.n_lanes = (uint32_t)lanes;
-        e2 = hipMemsetAsync(x.queue, 0, sizeof(uint32_t), ctx->stream);
+        x.lane_ws = buf.p; x.lane_ws_bytes = LL.total; x.lane_pathw = pathw; x.n_lanes = (uint32_t)lanes; x.lane_stride = stride;
+        x.queue = ws.d_small.p + 8 + which;
+        e2 = hipMemsetAsync(x.queue, 0, sizeof(uint32_t), st);
         if(e2 != hipSuccess) return e2;
-        return launch_wp_extend(ctx->fm, x, ctx->stream);
+        return launch_wp_extend(ctx->fm, x, st);
+    };
+
+    // The two-class schedule (wp_fast_kernel / wp_general_kernel): contexts = walks in flight.  Up to two pools (result-path
+    // classes) advance side by side, each on its own stream.
+    bool use_sched = false;
+    if(const char* ev = std::getenv("LRSC_WP_SCHED")) use_sched = std::atoi(ev) != 0;
+    uint32_t sched_budget_fast = 32, sched_budget_general = 24, sched_quorum = 25;
+    if(const char* ev = std::getenv("LRSC_WP_BUDGET_FAST")) sched_budget_fast = (uint32_t)std::max(1, std::atoi(ev));
+    if(const char* ev = std::getenv("LRSC_WP_BUDGET_GENERAL")) sched_budget_general = (uint32_t)std::max(1, std::atoi(ev));
+    if(const char* ev = std::getenv("LRSC_WP_QUORUM")) sched_quorum = (uint32_t)std::min(100, std::max(0, std::atoi(ev)));
+    uint64_t sched_rounds = 0;
+    struct Pool { WpSchedArgs sf, sg; uint32_t count = 0, lanes = 0; hipStream_t st = nullptr; bool done = true; };
+    auto pool_setup = [&](Pool& P, int which, const uint32_t* list, uint32_t count, uint32_t pathw, uint64_t budget_bytes, hipStream_t st) -> hipError_t {
+        P.count = count; P.st = st; P.done = count == 0;
+        if(count == 0) return hipSuccess;
+        const WpLaneLayout LL = wp_lane_layout(lbytes, pathw);
+        WpSchedArgs sa{};
+        sa.ctx_bytes = 64 + LL.total; sa.ctx_pathw = pathw;
+        uint64_t n_ctx = std::min<uint64_t>(count, 2ull * max_lanes);
+        n_ctx = std::max<uint64_t>(1, std::min<uint64_t>(n_ctx, budget_bytes / sa.ctx_bytes));
+        sa.n_ctx = (uint32_t)n_ctx;
+        hipError_t e2 = ws.d_ctx[which].reserve(n_ctx * sa.ctx_bytes);
+        if(e2 == hipSuccess) e2 = ws.d_sched.reserve(2);
+        if(e2 == hipSuccess) e2 = ws.d_sched_lists[which].reserve((size_t)kWpLists * n_ctx);
+        if(e2 != hipSuccess) return e2;
+        sa.sched = ws.d_sched.p + which; sa.fresh = list; sa.ctx_ws = ws.d_ctx[which].p;
+        sa.quorum_pct = sched_quorum;
+        e2 = launch_wp_sched_init(sa, ws.d_sched_lists[which].p, count, st);
+        if(e2 != hipSuccess) return e2;
+        P.lanes = (uint32_t)std::min<uint64_t>((n_ctx + 63) & ~63ull, max_lanes);
+        P.sf = sa; P.sg = sa;
+        P.sf.budget = sched_budget_fast; P.sg.budget = sched_budget_general;
+        return hipSuccess;
+    };
+    auto pools_run = [&](const WpArgs& x, Pool* pools, int n_pools) -> hipError_t {
+        for(uint32_t iter = 0;; ++iter) {
+            bool any = false;
+            for(int i = 0; i < n_pools; ++i) {
+                Pool& P = pools[i];
+                if(P.done) continue;
+                any = true;
+                // one round = fast kernel, general kernel (the two differ in their budget: steps / leaf-steps per pull)
+                hipError_t e2 = launch_wp_sched_round(ctx->fm, x, P.sf, P.sg, P.lanes, P.lanes, P.st);
+                if(e2 != hipSuccess) return e2;
+                ++sched_rounds;
+            }
+            if(!any) break;
+            if((iter & 3u) == 3u) {
+                uint32_t fin[2] = {0, 0};
+                for(int i = 0; i < n_pools; ++i)
+                    if(!pools[i].done) {
+                        hipError_t e2 = hipMemcpyAsync(&fin[i], &pools[i].sf.sched->finished, sizeof(uint32_t), hipMemcpyDeviceToHost, pools[i].st);
+                        if(e2 != hipSuccess) return e2;
+                    }
+                for(int i = 0; i < n_pools; ++i)
+                    if(!pools[i].done) {
+                        hipError_t e2 = hipStreamSynchronize(pools[i].st);
+                        if(e2 != hipSuccess) return e2;
+                        if(fin[i] >= pools[i].count) pools[i].done = true;
+                    }
+                if(iter > 4000000u) return hipErrorLaunchFailure;
+            }
+        }
+        return hipSuccess;
+    };
+    // everything on the side streams starts after what is on ctx->stream now, and ctx->stream goes on after them
+    auto side_begin = [&]() -> hipError_t {
+        hipError_t e2 = hipEventRecord(ws.ev_ready, ctx->stream);
+        for(int i = 0; i < 2 && e2 == hipSuccess; ++i) e2 = hipStreamWaitEvent(ws.side[i], ws.ev_ready, 0);
+        return e2;
+    };
+    auto side_join = [&]() -> hipError_t {
+        hipError_t e2 = hipSuccess;
+        for(int i = 0; i < 2 && e2 == hipSuccess; ++i) {
+            e2 = hipEventRecord(ws.ev_side[i], ws.side[i]);
+            if(e2 == hipSuccess) e2 = hipStreamWaitEvent(ctx->stream, ws.ev_side[i], 0);
+        }
+        return e2;
     };
 
     // ---- read ranges whose prepared tables fit the budget (about 40 bytes per query character + 6 KB per walk) -------------------
@@ -1706,13 +1814,32 @@ static int batch_correct_wp(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result* res,
                 hipError_t e2 = launch_wp_prepare(ctx->fm, a, ctx->stream);
                 if(e2 == hipSuccess) e2 = launch_wp_begin(ctx->fm, a, ctx->stream);
                 if(e2 != hipSuccess) return e2;
-                if(round == 0) {
-                    e2 = extend_range(a, ext_list, nullptr, n_big, stats[2]);
-                    if(e2 == hipSuccess) e2 = extend_range(a, ext_list + n_big, nullptr, n_mid - n_big, std::min(stats[2], kWpPathwMid));
-                    if(e2 == hipSuccess) e2 = extend_range(a, ext_list + n_mid, nullptr, n_ent - n_mid, std::min(stats[2], kWpPathwSmall));
+                if(!use_sched) {
+                    if(round != 0) return extend_range(a, a.list, a.reqs, n_ent, std::max(stats[2], 1u), ctx->stream, 0, n_ent < 4096 ? 64u : 1u);
+                    // the walks across long gaps (the first n_mid of the launch order): one per wavefront, beside the bulk
+                    e2 = side_begin();
+                    if(e2 == hipSuccess) e2 = extend_range(a, ext_list, nullptr, n_mid, stats[2], ws.side[0], 1, 64);
+                    if(e2 == hipSuccess) e2 = extend_range(a, ext_list + n_mid, nullptr, n_ent - n_mid, std::min(stats[2], kWpPathwSmall), ctx->stream, 0, 1);
+                    if(e2 == hipSuccess) e2 = side_join();
                     return e2;
                 }
-                return extend_range(a, a.list, a.reqs, n_ent, std::max(stats[2], 1u));
+                Pool pools[2];
+                e2 = side_begin();
+                if(e2 != hipSuccess) return e2;
+                if(round == 0) {
+                    // the few walks across the longest gaps: one-kernel form on a side stream; the mid class: its own pool on the other
+                    e2 = extend_range(a, ext_list, nullptr, n_big, stats[2], ws.side[0], 1, 64);
+                    if(e2 == hipSuccess) e2 = pool_setup(pools[0], 0, ext_list + n_mid, n_ent - n_mid, std::max(1u, std::min(stats[2], kWpPathwSmall)), lane_budget, ctx->stream);
+                    if(e2 == hipSuccess) e2 = pool_setup(pools[1], 1, ext_list + n_big, n_mid - n_big, std::max(1u, std::min(stats[2], kWpPathwMid)), lane_budget / 4, ws.side[1]);
+                } else if(stats[2] > kWpPathwMid)
+                    e2 = extend_range(a, a.list, a.reqs, n_ent, stats[2], ctx->stream, 0, 64);
+                else {
+                    // later rounds: a handful of re-queued walks, one pool (entries that are DP requests or carry a bad geometry end at once)
+                    e2 = pool_setup(pools[0], 0, a.list, n_ent, std::max(1u, stats[2]), lane_budget, ctx->stream);
+                }
+                if(e2 == hipSuccess) e2 = pools_run(a, pools, 2);
+                if(e2 == hipSuccess) e2 = side_join();
+                return e2;
             });
             if(st != LRSC_OK) return st;
 
@@ -1757,14 +1884,42 @@ static int batch_correct_wp(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result* res,
             e = launch_wp_stitch(a, ctx->stream);
             if(e != hipSuccess) return hip_fail(e, "wp_stitch");
             ++rounds_total;
+            if(verbose && round == 0 && std::getenv("LRSC_WP_DUMP")) {
+                // profiling aid: the hardest walks of the range (a walk is a chain of dependent steps: they bound the launch from below)
+                std::vector<WpSlot> hs(n_range);
+                HIP_TRY(hipStreamSynchronize(ctx->stream));
+                HIP_TRY(hipMemcpy(hs.data(), ws.d_slots.p + slot_base, (size_t)n_range * sizeof(WpSlot), hipMemcpyDeviceToHost));
+                std::vector<uint32_t> ord(n_range);
+                for(uint32_t i = 0; i < n_range; ++i) ord[i] = i;
+                std::sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) { return hs[x].leaf_steps > hs[y].leaf_steps; });
+                unsigned long long tot = 0, tot_steps = 0;
+                for(const WpSlot& q : hs) { tot += q.leaf_steps; tot_steps += q.steps; }
+                std::fprintf(stderr, "[lrsc] wp walks of the range: %u, %llu steps, %llu leaf-steps; hardest (gap, k, steps, leaf-steps, code):", n_range, tot_steps, tot);
+                for(uint32_t i = 0; i < std::min<uint32_t>(n_range, 12); ++i)
+                    std::fprintf(stderr, " (%u,%u,%u,%u,%d)", hs[ord[i]].gap, (unsigned)hs[ord[i]].k, hs[ord[i]].steps, hs[ord[i]].leaf_steps, hs[ord[i]].code);
+                const uint32_t qs[] = {n_range / 2, n_range / 10, n_range / 100, n_range / 1000, n_range / 10000};
+                std::fprintf(stderr, "; leaf-steps at the median / top 10%% / 1%% / 0.1%% / 0.01%%: %u %u %u %u %u\n", hs[ord[qs[0]]].leaf_steps, hs[ord[qs[1]]].leaf_steps,
+                             hs[ord[qs[2]]].leaf_steps, hs[ord[qs[3]]].leaf_steps, hs[ord[qs[4]]].leaf_steps);
+            }
             if(verbose)
-                std::fprintf(stderr, "[lrsc] wp reads [%u, %u) round %u: %u entries, %u DP requests (%llu strings), arenas q %.1f MB prep %.1f MB path %.1f MB\n",
-                             r0, r1, round, n_ent, n_items, (unsigned long long)stage.n_strings, tot[0] / 1048576.0, tot[1] / 1048576.0, tot[2] / 1048576.0);
+                std::fprintf(stderr, "[lrsc] wp reads [%u, %u) round %u: %u entries, %u DP requests (%llu strings), arenas q %.1f MB prep %.1f MB path %.1f MB, %llu schedule rounds so far\n",
+                             r0, r1, round, n_ent, n_items, (unsigned long long)stage.n_strings, tot[0] / 1048576.0, tot[1] / 1048576.0, tot[2] / 1048576.0,
+                             (unsigned long long)sched_rounds);
             if(round > 100000) return fail(LRSC_ERR_LIMIT, "walk-parallel flow: too many rounds");
         }
         r0 = r1;
     }
     (void)rounds_total;
+    if(a.prof) {
+        unsigned long long pr[16];
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipMemcpy(pr, ws.d_prof.p, sizeof(pr), hipMemcpyDeviceToHost));
+        const double all = (double)pr[10], st = (double)std::max<unsigned long long>(pr[11], 1);
+        std::fprintf(stderr, "[lrsc] wp extension kernel, lane wall ticks: %.3g total, %.0f per step over %.3g steps; extendLeaves %.1f%% (refine %.1f%%, attempToExtend %.1f%% of which "
+                             "getFMIndexExtensions %.1f%%), PrunedBySeedSupport %.1f%%, materialise+commit %.1f%%, isTerminated %.1f%%, refill %.1f%%, finish %.1f%%; single-leaf fast steps %.1f%% of the steps in %.1f%% of the ticks\n",
+                     all, all / st, st, 100 * pr[0] / all, 100 * pr[1] / all, 100 * pr[2] / all, 100 * pr[3] / all, 100 * pr[4] / all, 100 * pr[5] / all, 100 * pr[6] / all,
+                     100 * pr[8] / all, 100 * pr[9] / all, 100 * pr[12] / st, 100 * pr[7] / all);
+    }
     if(a.walk_log) b->walk_log_done = true;
 
     // ---- results ---------------------------------------------------------------------------------------------------------------------

@@ -199,7 +199,11 @@ struct Walk {
     WalkResultRec* results; uint32_t n_results;
     uint32_t ring_free, path_free;    // bit s: ring / path slot s is free (slot 0 belongs to the root's lineage)
     uint32_t n_rank, n_blk;
+    uint64_t alive_lo, alive_hi;      // PrunedBySeedSupport: bit c = child c survived (kMaxChildren = 128)
+    uint32_t has_child;               // ... bit i = leaf i of cur[] has a surviving child
+    uint32_t n_highfreq;              // children of the last attempToExtend whose k-mer frequency is above isInsufficientFreqs' threshold
     uint64_t steps;
+    uint32_t leaf_steps;              // frontier leaves summed over the steps (profiling)
     uint64_t cyc_setup, cyc_loop;     // profiling: ticks spent building the trees/root and in the extension loop
     uint64_t* prof;                   // profiling: ReadOut::cyc_step of the read, or nullptr
     __device__ __forceinline__ uint64_t tick() const { return prof ? __builtin_readcyclecounter() : 0; }
@@ -210,57 +214,125 @@ struct Walk {
 
     // findInterval of the leaf's suffix of length l on both strands (initialRootNode / refineSAInterval):
     // fwd = reverse(kmer) in the rbwt, rvc = revcomp(kmer) in the bwt; both consume kmer[0], kmer[1], ... in order
-    __device__ __noinline__ void find_suffix(Leaf<P>& lf, uint32_t l)
+    __device__ __forceinline__ void find_suffix_v(uint64_t slo, uint64_t shi, uint32_t l, P& flo, P& fhi, P& rlo, P& rhi)
     {
+        auto ch = [&](uint32_t t) -> uint32_t {
+            const uint32_t back = l - 1 - t;
+            return back < 32 ? (uint32_t)(slo >> (2 * back)) & 3u : (uint32_t)(shi >> (2 * (back - 32))) & 3u;
+        };
         WalkState<P> st = walk_init<P>();
-        const uint32_t t0 = table_start<WIDE>(*fm, [&](uint32_t t) { return suf_char(lf, l, t); }, l, st);
+        const uint32_t t0 = table_start<WIDE>(*fm, ch, l, st);
         for(uint32_t t = t0; t < l; ++t) {
             if(st.fwd_broken && st.rvc_broken) break;
-            st = walk_step<WIDE>(sF, sR, suf_char(lf, l, t), 1u << 30, st, mtab);
+            st = walk_step<WIDE>(sF, sR, ch(t), 1u << 30, st, mtab);
         }
         n_rank += st.n_rank; n_blk += st.n_blk;
-        lf.flo = st.fwd.lo; lf.fhi = st.fwd.hi; lf.rlo = st.rvc.lo; lf.rhi = st.rvc.hi;
+        flo = st.fwd.lo; fhi = st.fwd.hi; rlo = st.rvc.lo; rhi = st.rvc.hi;
+    }
+    __device__ __noinline__ void find_suffix(Leaf<P>& lf, uint32_t l)
+    {
+        P a, b, c, d;
+        find_suffix_v(lf.suf_lo, lf.suf_hi, l, a, b, c, d);
+        lf.flo = a; lf.fhi = b; lf.rlo = c; lf.rhi = d;
     }
 
-    __device__ void refineSAInterval(Leaf<P>* leaves, uint32_t n, uint64_t newKmerSize)   // .cpp:355-369
+    // refineSAInterval (.cpp:355-369).  The leaves' searches are independent: four run side by side, so that a dependent rank step
+    // of one leaf waits together with those of three others (a lane walks its frontier leaf by leaf otherwise)
+    __device__ __noinline__ void refineSAInterval(Leaf<P>* leaves, uint32_t n, uint64_t newKmerSize)
     {
-        for(uint32_t i = 0; i < n; ++i) find_suffix(leaves[i], (uint32_t)newKmerSize);
+        const uint32_t l = (uint32_t)newKmerSize;
+        for(uint32_t i0 = 0; i0 < n; i0 += 4) {
+            const uint32_t g = n - i0 < 4 ? n - i0 : 4;
+            uint64_t slo[4], shi[4];
+            WalkState<P> st[4];
+            uint32_t t0[4];
+#pragma unroll
+            for(uint32_t j = 0; j < 4; ++j) {
+                const uint32_t i = i0 + (j < g ? j : 0);
+                slo[j] = leaves[i].suf_lo; shi[j] = leaves[i].suf_hi;
+            }
+#pragma unroll
+            for(uint32_t j = 0; j < 4; ++j) {
+                st[j] = walk_init<P>();
+                const uint64_t a = slo[j], b = shi[j];
+                t0[j] = table_start<WIDE>(*fm, [&](uint32_t t) -> uint32_t {
+                    const uint32_t back = l - 1 - t;
+                    return back < 32 ? (uint32_t)(a >> (2 * back)) & 3u : (uint32_t)(b >> (2 * (back - 32))) & 3u; }, l, st[j]);
+            }
+            // every chain starts from the same table size (or from nothing): one shared loop counter
+            for(uint32_t t = t0[0]; t < l; ++t) {
+                bool any = false;
+#pragma unroll
+                for(uint32_t j = 0; j < 4; ++j) {
+                    if(j < g && !(st[j].fwd_broken && st[j].rvc_broken)) {
+                        const uint32_t back = l - 1 - t;
+                        const uint32_t c = back < 32 ? (uint32_t)(slo[j] >> (2 * back)) & 3u : (uint32_t)(shi[j] >> (2 * (back - 32))) & 3u;
+                        st[j] = walk_step<WIDE>(sF, sR, c, 1u << 30, st[j], mtab);
+                        any = true;
+                    }
+                }
+                if(!any) break;
+            }
+#pragma unroll
+            for(uint32_t j = 0; j < 4; ++j) {
+                if(j < g) {
+                    Leaf<P>& lf = leaves[i0 + j];
+                    n_rank += st[j].n_rank; n_blk += st[j].n_blk;
+                    lf.flo = st[j].fwd.lo; lf.fhi = st[j].fwd.hi; lf.rlo = st[j].rvc.lo; lf.rhi = st[j].rvc.hi;
+                }
+            }
+        }
         currentKmerSize = newKmerSize;
     }
 
     // ---- SelectFreqsOfrange (.cpp:281-331) ---------------------------------------------------------
+    // startkmer = last Lw chars of the suffix of length U; Fwd = findInterval(BWT, startkmer) walks it from
+    // its last character backwards; Rvc = findInterval(RBWT, complement(startkmer)) likewise.
+    // The pair is findBiInterval of x = revcomp(startkmer) with the strands' roles swapped (f walks the bwt with c, r the
+    // rbwt with 3 - c, both from the k-mer's last character backwards), so a k-mer table entry of x's first characters
+    // -- same early-exit semantics per strand -- replaces that many dependent rank steps.
+    __device__ __forceinline__ void select_first(uint64_t slo, uint64_t shi, uint32_t U, uint32_t Lw, IvT<P>& f, IvT<P>& r)
+    {
+        auto sc = [&](uint32_t t) -> uint32_t {                 // suf_char(lf, U, t)
+            const uint32_t back = U - 1 - t;
+            return back < 32 ? (uint32_t)(slo >> (2 * back)) & 3u : (uint32_t)(shi >> (2 * (back - 32))) & 3u;
+        };
+        bool fb = false, rb = false;
+        uint32_t t1 = 1;
+        {
+            WalkState<P> ts = walk_init<P>();
+            const uint32_t tk = table_start<WIDE>(*fm, [&](uint32_t t) { return 3u - sc(U - 1 - t); }, Lw, ts);
+            if(tk != 0) {
+                f = ts.rvc; r = ts.fwd; fb = ts.rvc_broken; rb = ts.fwd_broken; t1 = tk;
+            } else {
+                f = init_interval<P>(sR, sc(U - 1));
+                r = init_interval<P>(sF, 3u - sc(U - 1));
+                n_rank += 2;
+            }
+        }
+        for(uint32_t t = t1; t < Lw; ++t) {
+            if(fb && rb) break;
+            const uint32_t c = sc(U - 1 - t);
+            if(!fb) { f = upd(sR, c, f); fb = f.lo > f.hi; }
+            if(!rb) { r = upd(sF, 3u - c, r); rb = r.lo > r.hi; }
+            if(fb && rb) break;
+        }
+    }
+    __device__ __forceinline__ void select_next(uint64_t slo, uint64_t shi, uint32_t U, uint32_t t, IvT<P>& f, IvT<P>& r)
+    {
+        const uint32_t back = U - 1 - t;
+        const uint32_t b = back < 32 ? (uint32_t)(slo >> (2 * back)) & 3u : (uint32_t)(shi >> (2 * (back - 32))) & 3u;
+        f = upd(sR, b, f);                           // no validity check here (.cpp:317-318)
+        r = upd(sF, 3u - b, r);
+    }
     __device__ __noinline__ uint64_t SelectFreqsOfrange(uint64_t LowerBound, uint64_t UpperBound, Leaf<P>* leaves, uint32_t n)
     {
         int tempmaxfmfreqs = 0;
         const uint32_t U = (uint32_t)UpperBound, Lw = (uint32_t)LowerBound;
         for(uint32_t j = 0; j < n; ++j) {
             Leaf<P>& lf = leaves[j];
-            // startkmer = last Lw chars of the suffix of length U; Fwd = findInterval(BWT, startkmer) walks it from
-            // its last character backwards; Rvc = findInterval(RBWT, complement(startkmer)) likewise
-            // The pair is findBiInterval of x = revcomp(startkmer) with the strands' roles swapped (f walks the bwt with c, r the
-            // rbwt with 3 - c, both from the k-mer's last character backwards), so a k-mer table entry of x's first characters
-            // -- same early-exit semantics per strand -- replaces that many dependent rank steps.
             IvT<P> f, r;
-            bool fb = false, rb = false;
-            uint32_t t1 = 1;
-            {
-                WalkState<P> ts = walk_init<P>();
-                const uint32_t tk = table_start<WIDE>(*fm, [&](uint32_t t) { return 3u - suf_char(lf, U, U - 1 - t); }, Lw, ts);
-                if(tk != 0) {
-                    f = ts.rvc; r = ts.fwd; fb = ts.rvc_broken; rb = ts.fwd_broken; t1 = tk;
-                } else {
-                    f = init_interval<P>(sR, suf_char(lf, U, U - 1));
-                    r = init_interval<P>(sF, 3u - suf_char(lf, U, U - 1));
-                    n_rank += 2;
-                }
-            }
-            for(uint32_t t = t1; t < Lw; ++t) {
-                if(fb && rb) break;
-                const uint32_t c = suf_char(lf, U, U - 1 - t);
-                if(!fb) { f = upd(sR, c, f); fb = f.lo > f.hi; }
-                if(!rb) { r = upd(sF, 3u - c, r); rb = r.lo > r.hi; }
-                if(fb && rb) break;
-            }
+            select_first(lf.suf_lo, lf.suf_hi, U, Lw, f, r);
             lf.tflo = f.lo; lf.tfhi = f.hi; lf.trlo = r.lo; lf.trhi = r.hi;
             lf.tmpFreq = (int)(isize(f.lo, f.hi) + isize(r.lo, r.hi));
             if(lf.tmpFreq > tempmaxfmfreqs) tempmaxfmfreqs = lf.tmpFreq;
@@ -271,10 +343,8 @@ struct Walk {
             tempmaxfmfreqs = 0;
             for(uint32_t j = 0; j < n; ++j) {
                 Leaf<P>& lf = leaves[j];
-                const uint32_t b = suf_char(lf, U, (uint32_t)(UpperBound - LowerBound - i));
                 IvT<P> f{lf.tflo, lf.tfhi}, r{lf.trlo, lf.trhi};
-                f = upd(sR, b, f);                           // no validity check here (.cpp:317-318)
-                r = upd(sF, 3u - b, r);
+                select_next(lf.suf_lo, lf.suf_hi, U, (uint32_t)(UpperBound - LowerBound - i), f, r);
                 lf.tflo = f.lo; lf.tfhi = f.hi; lf.trlo = r.lo; lf.trhi = r.hi;
                 lf.tmpFreq = (int)(isize(f.lo, f.hi) + isize(r.lo, r.hi));
                 if(lf.tmpFreq > tempmaxfmfreqs) tempmaxfmfreqs = lf.tmpFreq;
@@ -283,14 +353,27 @@ struct Walk {
         }
         return UpperBound;
     }
-
-    __device__ bool isInsufficientFreqs(const Leaf<P>* leaves, uint32_t n)     // .cpp:334-352
+    // the same for a frontier of one leaf, on values (the leaf's tf* scratch fields are write-only outside this function)
+    __device__ __forceinline__ uint64_t SelectFreqsOfrange1(uint64_t LowerBound, uint64_t UpperBound, uint64_t slo, uint64_t shi)
     {
-        uint64_t highfreqscount = 0;
-        for(uint32_t i = 0; i < n; ++i) {
-            const int highfreqThreshold = PBcoverage > 60 ? (int)((uint64_t)(PBcoverage / 60) * 3) : 3;
-            if(leaves[i].kmerFrequency > highfreqThreshold) highfreqscount++;
+        const uint32_t U = (uint32_t)UpperBound, Lw = (uint32_t)LowerBound;
+        IvT<P> f, r;
+        select_first(slo, shi, U, Lw, f, r);
+        int freq = (int)(isize(f.lo, f.hi) + isize(r.lo, r.hi));
+        int tempmaxfmfreqs = freq > 0 ? freq : 0;
+        if(tempmaxfmfreqs - (int)freqsOfKmerSize[LowerBound] < 5) return LowerBound;
+        for(uint64_t i = 1; i <= UpperBound - LowerBound; i++) {
+            select_next(slo, shi, U, (uint32_t)(UpperBound - LowerBound - i), f, r);
+            freq = (int)(isize(f.lo, f.hi) + isize(r.lo, r.hi));
+            tempmaxfmfreqs = freq > 0 ? freq : 0;
+            if(tempmaxfmfreqs - (int)freqsOfKmerSize[LowerBound + i] < 5) return LowerBound + i;
         }
+        return UpperBound;
+    }
+
+    // isInsufficientFreqs (.cpp:334-352) over the children attempToExtend has just made: it counted those above the threshold
+    __device__ bool isInsufficientFreqs(uint64_t highfreqscount, uint32_t n)
+    {
         if(highfreqscount == 0) return true;
         else if(highfreqscount <= 2 && n >= 5) return true;
         else if(highfreqscount <= 1 && n >= 3) return true;
@@ -313,8 +396,14 @@ struct Walk {
 
     // ---- getFMIndexExtensions (.cpp:667-784): returns a bit mask of accepted bases, fills ext[] -------------
     struct Ext { IvT<P> f, r; int freq; };
-    __device__ uint32_t getFMIndexExtensions(const Leaf<P>& lf, Ext ext[4], uint64_t& totalcount_out)
+    __device__ __forceinline__ uint32_t getFMIndexExtensions(const Leaf<P>& lf, Ext ext[4], uint64_t& totalcount_out)
     {
+        return getFMIndexExtensions_v(lf.flo, lf.fhi, lf.rlo, lf.rhi, lf.tailLetterCount, lf.suf_lo, ext, totalcount_out);
+    }
+    __device__ __forceinline__ uint32_t getFMIndexExtensions_v(P lf_flo, P lf_fhi, P lf_rlo, P lf_rhi, uint32_t lf_tailLetterCount, uint64_t lf_suf_lo,
+                                                               Ext ext[4], uint64_t& totalcount_out)
+    {
+        struct { P flo, fhi, rlo, rhi; uint32_t tailLetterCount; uint64_t suf_lo; } lf{lf_flo, lf_fhi, lf_rlo, lf_rhi, lf_tailLetterCount, lf_suf_lo};
         const uint64_t IntervalSizeCutoff = min_SA_threshold;
         uint64_t totalcount = 0;
         int maxfreqsofleave = 0;
@@ -373,8 +462,13 @@ struct Walk {
     __device__ void attempToExtend()
     {
         double minimumErrorRate = 1;
-        for(uint32_t i = 0; i < n_cur; ++i)
-            if(cur[i].localErr < minimumErrorRate) minimumErrorRate = cur[i].localErr;
+        for(uint32_t i = 0; i < n_cur; i += 4) {                 // four loads in flight, same comparisons in the same order
+            double e[4];
+#pragma unroll
+            for(uint32_t j = 0; j < 4; ++j) e[j] = cur[i + j < n_cur ? i + j : i].localErr;
+#pragma unroll
+            for(uint32_t j = 0; j < 4; ++j) if(i + j < n_cur && e[j] < minimumErrorRate) minimumErrorRate = e[j];
+        }
         // trim leaves whose error rate relative to the best one is high
         uint32_t w = 0;
         for(uint32_t i = 0; i < n_cur; ++i) {
@@ -388,15 +482,18 @@ struct Walk {
         }
         n_cur = w;
 
+        n_highfreq = 0;
+        const int highfreqThreshold = PBcoverage > 60 ? (int)((uint64_t)(PBcoverage / 60) * 3) : 3;
         for(uint32_t i = 0; i < n_cur; ++i) {
+            const Leaf<P> par = cur[i];                          // one burst of loads: the leaf in registers
             Ext ext[4];
             uint32_t mask = 0;
             int count = 0;
             while(count < 2) {
-                if(count == 1 && !(cur[i].localErr == minimumErrorRate && n_cur > 1)) break;
+                if(count == 1 && !(par.localErr == minimumErrorRate && n_cur > 1)) break;
                 uint64_t tc;
                 const uint64_t tg = tick();
-                mask = getFMIndexExtensions(cur[i], ext, tc);
+                mask = getFMIndexExtensions_v(par.flo, par.fhi, par.rlo, par.rhi, par.tailLetterCount, par.suf_lo, ext, tc);
                 tock(3, tg);
                 if(mask != 0) break;
                 min_SA_threshold--;
@@ -408,18 +505,19 @@ struct Walk {
             for(uint32_t b = 0; b < 4; ++b) {
                 if(!(mask & (1u << b))) continue;
                 if(n_nxt >= kMaxChildren) { error = LRSC_WALK_ERR_CHILDREN; return; }
-                Leaf<P>& ch = nxt[n_nxt++];
-                ch = cur[i];                               // createChild copies the node state (SAINode.cpp:166-189)
+                Leaf<P> ch = par;                                  // createChild copies the node state (SAINode.cpp:166-189)
                 ch.flo = ext[b].f.lo; ch.fhi = ext[b].f.hi; ch.rlo = ext[b].r.lo; ch.rhi = ext[b].r.hi;
                 ch.kmerFrequency = ext[b].freq;
                 ch.currOverlapLen++;
                 ch.queryOverlapLen++;
-                if(cur[i].tailLetter == b) ch.tailLetterCount = cur[i].tailLetterCount + 1;
+                if(par.tailLetter == b) ch.tailLetterCount = par.tailLetterCount + 1;
                 else { ch.tailLetter = b; ch.tailLetterCount = 1; }
                 suf_push(ch, b);
                 ch.parent = (uint16_t)i;
                 ch.ext = (uint8_t)b;
                 ch.alive = 1;
+                if(ch.kmerFrequency > highfreqThreshold) n_highfreq++;      // for isInsufficientFreqs, which looks at exactly these values
+                nxt[n_nxt++] = ch;
             }
         }
     }
@@ -451,7 +549,7 @@ struct Walk {
         if(n_nxt != 0) {
             currentLength++;
             currentKmerSize++;
-            if(isInsufficientFreqs(nxt, n_nxt)) {           // frequencies are low: relax the k-mer size
+            if(isInsufficientFreqs(n_highfreq, n_nxt)) {    // frequencies are low: relax the k-mer size
                 const uint64_t LowerBound = (currentKmerSize - 2) > minOverlap ? (currentKmerSize - 2) : minOverlap;
                 const uint64_t ReduceSize = SelectFreqsOfrange(LowerBound, currentKmerSize, nxt, n_nxt);
                 refineSAInterval(nxt, n_nxt, ReduceSize);
@@ -461,6 +559,10 @@ struct Walk {
 
     // ---- isSupportedByNewSeed (.cpp:566-635) ------------------------------------------------------------------
     __device__ __noinline__ bool isSupportedByNewSeed(Leaf<P>& nd, uint64_t smallSeedIdx, uint64_t largeSeedIdx)
+    {
+        return seed_support_core(nd, smallSeedIdx, largeSeedIdx);
+    }
+    __device__ __forceinline__ bool seed_support_core(Leaf<P>& nd, uint64_t smallSeedIdx, uint64_t largeSeedIdx)
     {
         const uint64_t seedIdxOffset = nd.lastOverlapLen < currentLength - seedSize ? (uint64_t)seedSize : currentLength - nd.lastOverlapLen;
         const uint64_t cand = nd.lastSeedIdx + seedIdxOffset;
@@ -531,32 +633,40 @@ struct Walk {
     }
 
     // ---- PrunedBySeedSupport (.cpp:491-563) ------------------------------------------------------------------
+    template <bool INLINE>
+    __device__ __forceinline__ void prune_leaf(Leaf<P>& leaf, const double* pring, uint64_t currSeedIdx, uint64_t smallSeedIdx, uint64_t largeSeedIdx)
+    {
+        bool isNewSeedFound = false;
+        if(currentLength - leaf.lastOverlapLen > seedSize || currentLength - leaf.lastOverlapLen <= 1) {
+            const uint64_t preSeedIdx = leaf.lastSeedIdx;
+            isNewSeedFound = INLINE ? seed_support_core(leaf, smallSeedIdx, largeSeedIdx) : isSupportedByNewSeed(leaf, smallSeedIdx, largeSeedIdx);
+            if(isNewSeedFound) {
+                if(currSeedIdx + (uint64_t)(int64_t)leaf.lastSeedIdxOffset - preSeedIdx > seedSize)
+                    leaf.numRedeemSeed += (seedSize - 1) * PacBioErrorRate;
+                leaf.lastSeedIdxOffset = (int)leaf.lastSeedIdx - (int)currSeedIdx;
+            } else {
+                const uint64_t v = currSeedIdx + (uint64_t)(int64_t)leaf.lastSeedIdxOffset - leaf.lastSeedIdx;
+                if(v % seedSize == 1) leaf.numOfErrors++;
+                else if(v > (uint64_t)seedSize - 1) leaf.numRedeemSeed += 1 - PacBioErrorRate;
+            }
+        } else
+            leaf.numRedeemSeed += 1 - PacBioErrorRate;
+        const double currErrorRate = computeErrorRate(leaf, pring);
+        if(currErrorRate > errorRate) leaf.alive = 0;
+    }
     __device__ void PrunedBySeedSupport()
     {
         const uint64_t currSeedIdx = currentLength - seedSize;
         const uint64_t indelOffset = seedSize + maxIndelSize;
         const uint64_t smallSeedIdx = currSeedIdx <= indelOffset ? 0 : currSeedIdx - indelOffset;
         const uint64_t largeSeedIdx = (currSeedIdx + indelOffset) >= (Lq - seedSize) ? (Lq - seedSize) : currSeedIdx + indelOffset;
+        alive_lo = 0; alive_hi = 0; has_child = 0;
         for(uint32_t c = 0; c < n_nxt; ++c) {
-            Leaf<P>& leaf = nxt[c];
-            bool isNewSeedFound = false;
-            if(currentLength - leaf.lastOverlapLen > seedSize || currentLength - leaf.lastOverlapLen <= 1) {
-                const uint64_t preSeedIdx = leaf.lastSeedIdx;
-                isNewSeedFound = isSupportedByNewSeed(leaf, smallSeedIdx, largeSeedIdx);
-                if(isNewSeedFound) {
-                    if(currSeedIdx + (uint64_t)(int64_t)leaf.lastSeedIdxOffset - preSeedIdx > seedSize)
-                        leaf.numRedeemSeed += (seedSize - 1) * PacBioErrorRate;
-                    leaf.lastSeedIdxOffset = (int)leaf.lastSeedIdx - (int)currSeedIdx;
-                } else {
-                    const uint64_t v = currSeedIdx + (uint64_t)(int64_t)leaf.lastSeedIdxOffset - leaf.lastSeedIdx;
-                    if(v % seedSize == 1) leaf.numOfErrors++;
-                    else if(v > (uint64_t)seedSize - 1) leaf.numRedeemSeed += 1 - PacBioErrorRate;
-                }
-            } else
-                leaf.numRedeemSeed += 1 - PacBioErrorRate;
-            const double* pring = rings + (uint64_t)cur[leaf.parent].ring * 100;
-            const double currErrorRate = computeErrorRate(leaf, pring);
-            if(currErrorRate > errorRate) leaf.alive = 0;
+            Leaf<P> leaf = nxt[c];                               // in registers for the whole evaluation, one burst each way
+            // createChild copied the parent's ring id into the child: cur[leaf.parent].ring == leaf.ring until the commit
+            prune_leaf<true>(leaf, rings + (uint64_t)leaf.ring * 100, currSeedIdx, smallSeedIdx, largeSeedIdx);
+            nxt[c] = leaf;
+            if(leaf.alive) { if(c < 64) alive_lo |= 1ull << c; else alive_hi |= 1ull << (c - 64); has_child |= 1u << leaf.parent; }
         }
     }
 
@@ -704,10 +814,101 @@ struct Walk {
         cyc_setup += __builtin_readcyclecounter() - t_run0;
     }
 
+    // ---------------------------------------------------------------------------------------------------------
+    // Single-leaf fast path.  While the frontier is ONE leaf (most steps: 1.36 leaves per step on average) the leaf lives in
+    // registers (`L`) between steps, and a step touches memory only for what the algorithm itself reads: rank blocks, k-mer table
+    // entries, the query's 9-mer chains, one error-history ring slot, one path word.  Same arithmetic in the same order as the
+    // general step (extendLeaves / PrunedBySeedSupport / the commit in step_body); a step that is not of the simple kind -- no
+    // accepted base, more than one -- is handed to the general code BEFORE it has had any effect.
+    // ---------------------------------------------------------------------------------------------------------
+    __device__ __forceinline__ bool can_fast() const { return !ended && !error && n_cur == 1; }
+    __device__ __forceinline__ void enter_fast(Leaf<P>& L, uint32_t& pw)
+    {
+        L = cur[0];
+        pw = (L.path_len & 15u) ? paths[(uint64_t)L.path * pathw + (L.path_len >> 4)] : 0u;
+    }
+    __device__ __forceinline__ void leave_fast(const Leaf<P>& L) { cur[0] = L; }
+    // 1: step done, the frontier is still the one leaf in L;  0: extendOverlap's loop is over (L written back, finish() decides);
+    // 2: not a simple step -- nothing has happened, L written back: run the general step()
+    __device__ __forceinline__ int step_fast(Leaf<P>& L, uint32_t& pw)
+    {
+        if(!(currentLength <= maxLength)) { leave_fast(L); return 0; }
+        // attempToExtend's trimming never fires for one leaf unless its local error rate is >= 1 (the minimum starts at 1): general code
+        if(!(L.localErr < 1.0)) { leave_fast(L); return 2; }
+        const uint32_t nr0 = n_rank, nb0 = n_blk;
+        // --- extendLeaves (.cpp:239-278) ---
+        uint64_t ck = currentKmerSize;
+        P flo = L.flo, fhi = L.fhi, rlo = L.rlo, rhi = L.rhi;
+        if(ck > maxOverlap) { find_suffix_v(L.suf_lo, L.suf_hi, (uint32_t)maxOverlap, flo, fhi, rlo, rhi); ck = maxOverlap; }
+        Ext ext[4];
+        uint64_t tc;
+        const uint32_t mask = getFMIndexExtensions_v(flo, fhi, rlo, rhi, L.tailLetterCount, L.suf_lo, ext, tc);
+        if(mask == 0 || (mask & (mask - 1u)) != 0) { n_rank = nr0; n_blk = nb0; leave_fast(L); return 2; }
+        const uint32_t b = (uint32_t)__builtin_ctz(mask);
+        // updateLeaves: the one child (createChild + leafInfo ctor)
+        L.flo = ext[b].f.lo; L.fhi = ext[b].f.hi; L.rlo = ext[b].r.lo; L.rhi = ext[b].r.hi;
+        L.kmerFrequency = ext[b].freq;
+        L.currOverlapLen++;
+        L.queryOverlapLen++;
+        if(L.tailLetter == b) L.tailLetterCount = L.tailLetterCount + 1;
+        else { L.tailLetter = b; L.tailLetterCount = 1; }
+        suf_push(L, b);
+        L.parent = 0; L.ext = (uint8_t)b; L.alive = 1;
+        currentLength++;
+        ck++;
+        {   // isInsufficientFreqs for one leaf: no k-mer above the threshold
+            const int highfreqThreshold = PBcoverage > 60 ? (int)((uint64_t)(PBcoverage / 60) * 3) : 3;
+            if(!(L.kmerFrequency > highfreqThreshold)) {
+                const uint64_t LowerBound = (ck - 2) > minOverlap ? (ck - 2) : minOverlap;
+                const uint64_t ReduceSize = SelectFreqsOfrange1(LowerBound, ck, L.suf_lo, L.suf_hi);
+                find_suffix_v(L.suf_lo, L.suf_hi, (uint32_t)ReduceSize, L.flo, L.fhi, L.rlo, L.rhi);
+                ck = ReduceSize;
+            }
+        }
+        currentKmerSize = ck;
+        // --- PrunedBySeedSupport ---
+        {
+            const uint64_t currSeedIdx = currentLength - seedSize;
+            const uint64_t indelOffset = seedSize + maxIndelSize;
+            const uint64_t smallSeedIdx = currSeedIdx <= indelOffset ? 0 : currSeedIdx - indelOffset;
+            const uint64_t largeSeedIdx = (currSeedIdx + indelOffset) >= (Lq - seedSize) ? (Lq - seedSize) : currSeedIdx + indelOffset;
+            prune_leaf<true>(L, rings + (uint64_t)L.ring * 100, currSeedIdx, smallSeedIdx, largeSeedIdx);
+        }
+        ++steps; ++leaf_steps;
+        if(!L.alive) { leave_fast(L); n_cur = 0; return 0; }         // the frontier is empty: "high error"
+        // --- commit: the child takes over its parent's ring and path in place ---
+        rings[(uint64_t)L.ring * 100 + (L.hist_size - 1) % 100] = L.globalErr;     // GlobalErrorRateRecord.push_back
+        {
+            const uint32_t sh = 2 * (L.path_len & 15u);
+            if(sh == 0) pw = 0;
+            pw = (pw & ~(3u << sh)) | (b << sh);
+            paths[(uint64_t)L.path * pathw + (L.path_len >> 4)] = pw;
+            L.path_len++;
+        }
+        // --- isTerminated ---
+        if(currentLength >= minLength) {
+            bool may_hit = true;
+            if(currentKmerSize >= minOverlap) {
+                const uint32_t Lm = minOverlap < 16 ? (uint32_t)minOverlap : 16u;
+                const uint32_t code = (uint32_t)(L.suf_lo & (Lm >= 16 ? 0xFFFFFFFFull : ((1ull << (2 * Lm)) - 1ull)));
+                const uint32_t h = (code * 0x9E3779B1u) >> 25;
+                may_hit = (((h < 64 ? tmask0 : tmask1) >> (h & 63u)) & 1ull) != 0;
+            }
+            if(may_hit) {
+                leave_fast(L);
+                terminated_leaf(cur[0], paths + (uint64_t)L.path * pathw, L.path_len, -1);
+                if(error) return 0;
+                L.res_first = cur[0].res_first; L.res_second = cur[0].res_second;
+            }
+        }
+        return 1;
+    }
+
     // one iteration of extendOverlap's loop (.cpp:155-211); false when the loop is over (or on an internal error)
     __device__ bool step()
     {
         if(ended || error || !(n_cur != 0 && n_cur <= maxLeaves && currentLength <= maxLength)) return false;
+        leaf_steps += n_cur;
         if(profile) {                                    // two s_memtime round trips per step are not free: only when asked for
             const uint64_t t_step0 = __builtin_readcyclecounter();
             step_body();
@@ -728,14 +929,14 @@ struct Walk {
             PrunedBySeedSupport();
             tock(4, t);
             t = tick();
-            uint32_t survivors = 0;
-            for(uint32_t c = 0; c < n_nxt; ++c) survivors += nxt[c].alive;
+            const uint32_t survivors = (uint32_t)(__builtin_popcountll(alive_lo) + __builtin_popcountll(alive_hi));
+            auto is_alive = [&](uint32_t c) -> bool { return ((c < 64 ? alive_lo >> c : alive_hi >> (c - 64)) & 1ull) != 0; };
             ++steps;
             if(survivors > maxLeaves) {
                 // the frontier overflows: the loop ends after this isTerminated, no leaf state is needed any more
                 if(currentLength >= minLength)
                     for(uint32_t c = 0; c < n_nxt; ++c) {
-                        if(!nxt[c].alive) continue;
+                        if(!is_alive(c)) continue;
                         const Leaf<P>& par = cur[nxt[c].parent];
                         terminated_leaf(nxt[c], paths + (uint64_t)par.path * pathw, par.path_len, (int)nxt[c].ext);
                         if(error) return;
@@ -745,37 +946,38 @@ struct Walk {
                 return;
             }
             // materialise the survivors: the first surviving child of a parent takes over its ring and path
-            // in place (SAINode::extend), further ones get copies (createChild)
-            uint32_t has_child = 0;                         // bit i: leaf i of cur[] has a surviving child (n_cur <= 32)
-            for(uint32_t c = 0; c < n_nxt; ++c) if(nxt[c].alive) has_child |= 1u << nxt[c].parent;
+            // in place (SAINode::extend), further ones get copies (createChild).  A child still carries its parent's
+            // ring / path ids and path length (createChild copied them), so the parent need not be read again.
+            // has_child (from PrunedBySeedSupport): bit i = leaf i of cur[] has a surviving child (n_cur <= 32)
             for(uint32_t i = 0; i < n_cur; ++i) if(!((has_child >> i) & 1u)) free_leaf_slots(cur[i]);
-            // copies first (they read the parent's buffers before the in-place child appends to them)
-            uint32_t seen = 0;
+            const bool want_term = currentLength >= minLength;
+            uint32_t seen = 0, w = 0;
             for(uint32_t c = 0; c < n_nxt; ++c) {
-                Leaf<P>& ch = nxt[c];
-                if(!ch.alive) continue;
-                const Leaf<P>& par = cur[ch.parent];
-                if(!((seen >> ch.parent) & 1u)) { seen |= 1u << ch.parent; ch.ring = par.ring; ch.path = par.path; continue; }
-                ch.ring = (uint16_t)__builtin_ctz(ring_free); ring_free &= ring_free - 1u;     // survivors <= 32 slots: never empty here
-                ch.path = (uint16_t)__builtin_ctz(path_free); path_free &= path_free - 1u;
-                const double* src = rings + (uint64_t)par.ring * 100;
-                double* dst = rings + (uint64_t)ch.ring * 100;
-                for(uint32_t k = 0; k < 100; ++k) dst[k] = src[k];
-                const uint32_t* ps = paths + (uint64_t)par.path * pathw;
-                uint32_t* pd = paths + (uint64_t)ch.path * pathw;
-                const uint32_t nw = (par.path_len + 16) >> 4;
-                for(uint32_t k = 0; k < nw; ++k) pd[k] = ps[k];
-            }
-            uint32_t w = 0;
-            for(uint32_t c = 0; c < n_nxt; ++c) {
-                Leaf<P>& ch = nxt[c];
-                if(!ch.alive) continue;
+                if(!is_alive(c)) continue;
+                Leaf<P> ch = nxt[c];                             // registers: one burst in, one out
+                if((seen >> ch.parent) & 1u) {
+                    // a further child of this parent: copies of the ring and of the path as they are BEFORE this step's appends
+                    // (the in-place child of the parent has only written slots the copies do not read: see below)
+                    const uint16_t pr = ch.ring, pp = ch.path;
+                    ch.ring = (uint16_t)__builtin_ctz(ring_free); ring_free &= ring_free - 1u;     // survivors <= 32 slots: never empty here
+                    ch.path = (uint16_t)__builtin_ctz(path_free); path_free &= path_free - 1u;
+                    const double* src = rings + (uint64_t)pr * 100;
+                    double* dst = rings + (uint64_t)ch.ring * 100;
+                    const uint32_t own = (ch.hist_size - 1) % 100;                 // the slot this child overwrites anyway
+                    for(uint32_t k = 0; k < 100; ++k) if(k != own) dst[k] = src[k];
+                    const uint32_t* ps = paths + (uint64_t)pp * pathw;
+                    uint32_t* pd = paths + (uint64_t)ch.path * pathw;
+                    const uint32_t nw = (ch.path_len + 16) >> 4;
+                    for(uint32_t k = 0; k < nw; ++k) pd[k] = ps[k];
+                }
+                seen |= 1u << ch.parent;
                 rings[(uint64_t)ch.ring * 100 + (ch.hist_size - 1) % 100] = ch.globalErr;     // GlobalErrorRateRecord.push_back
                 path_set(paths + (uint64_t)ch.path * pathw, ch.path_len, ch.ext);
                 ch.path_len++;
-                if(w != c) nxt[w] = ch;                       // compaction; a survivor that already sits in place is not copied onto itself
+                nxt[w] = ch;                                       // compaction
                 ++w;
             }
+            (void)want_term;
             // m_leaves = newLeaves: the two leaf buffers trade places when the old `cur` region (32 or kMaxChildren slots) can take
             // the next step's children (4 per survivor); otherwise the survivors are copied down as before
             if(4u * w <= (cur == leaf_small ? 32u : kMaxChildren)) { Leaf<P>* t2 = cur; cur = nxt; nxt = t2; }

@@ -44,7 +44,7 @@ struct alignas(16) WpSlot {
     int32_t code;
     uint32_t path_len, match_i, steps;
     // DP result
-    uint32_t dp_rows, dp_cons_len, dp_error, pad3;
+    uint32_t dp_rows, dp_cons_len, dp_error, leaf_steps;   // leaf_steps: frontier leaves summed over the attempt's steps (profiling)
     const uint8_t* dp_cons;
 };
 
@@ -155,6 +155,8 @@ struct WpArgs {
     uint32_t* queue;             // next list entry to hand out
     uint8_t* lane_ws;
     uint32_t lane_ws_bytes, lane_pathw, n_lanes;
+    uint32_t lane_stride;        // 1: every lane of a wavefront runs walks; 64: one walk per wavefront (the few very long walks: a lane-per-walk
+                                 // wavefront advances at the pace of its slowest lane, and these are thousands of wide steps long)
     uint32_t auto_dp;            // a failed walk with next == 0 goes to the DP stage in the same round
     WpDpItem* dp_items;
     uint32_t* n_dp_items;
@@ -172,15 +174,56 @@ struct WpArgs {
     uint32_t req_cap;
     uint8_t* walk_log;
     DevCounters* ctr;
+    unsigned long long* prof;    // LRSC_CORRECT_PROFILE: 16 tick totals of the extension kernel (per-lane wall ticks summed over lanes)
 };
 
-constexpr uint32_t kWpPathwSmall = 48, kWpPathwMid = 256;
+constexpr uint32_t kWpPathwSmall = 64, kWpPathwMid = 256;
+
+// ---- the two-class schedule of the extension (wp_fast_kernel / wp_general_kernel) ---------------------------------------------
+// A walk in flight owns a CONTEXT: its dynamic workspace (WpLaneLayout) headed by a WpCtx with the few scalars of the Walk
+// object that change from step to step.  Between launches every walk in flight sits in one of three lists:
+//   FAST     its frontier is one leaf: the next step is of the single-leaf kind (Walk::step_fast, leaf in registers)
+//   GENERAL  anything else (several leaves, no accepted base, ...): the general step over the frontier in memory
+//   FREE     contexts without a walk
+// wp_fast_kernel's lanes pull FAST entries (then fresh walks onto FREE contexts) and step them until they leave the single-leaf
+// regime, end, or use up a step budget; wp_general_kernel's lanes do the same for GENERAL entries.  Each kernel therefore runs
+// ONE kind of step in all its lanes, instead of every wavefront paying for both kinds in every iteration.
+struct WpCtx {
+    uint32_t slot;
+    uint32_t currentLength, currentKmerSize;
+    uint32_t n_cur, n_results;
+    uint32_t ring_free, path_free;
+    uint32_t steps;
+    uint32_t cur_is_small, ended;
+    int32_t error;
+    uint32_t pad;
+};
+struct WpList { uint32_t* items; uint32_t n, cursor; };
+enum { kWpFastA = 0, kWpFastB = 1, kWpGenA = 2, kWpGenB = 3, kWpFreeA = 4, kWpFreeB = 5, kWpLists = 6 };
+struct WpSched {
+    WpList list[kWpLists];
+    uint32_t fresh_cursor, n_fresh;      // fresh walks: entries [0, n_fresh) of WpSchedArgs::fresh
+    uint32_t finished;
+    uint32_t round;
+};
+struct WpSchedArgs {
+    WpSched* sched;
+    const uint32_t* fresh;               // slot indexes of the walks to run (launch order)
+    uint8_t* ctx_ws;                     // n_ctx contexts of ctx_bytes each: WpCtx, then the WpLaneLayout regions (pathw = ctx_pathw)
+    uint32_t ctx_bytes, ctx_pathw, n_ctx;
+    uint32_t budget;                     // steps a lane gives one walk before it hands it back
+    uint32_t quorum_pct;                 // idle lanes (in %) of a wavefront that wait for company before they pull their next walks
+};
 
 hipError_t launch_wp_plan(const WpArgs& a, hipStream_t stream);
 hipError_t launch_wp_materialize(const WpArgs& a, hipStream_t stream);
 hipError_t launch_wp_prepare(const FmIndexDev& fm, const WpArgs& a, hipStream_t stream);
 hipError_t launch_wp_begin(const FmIndexDev& fm, const WpArgs& a, hipStream_t stream);
 hipError_t launch_wp_extend(const FmIndexDev& fm, const WpArgs& a, hipStream_t stream);
+// one round of the two-class schedule: fast kernel, list rotation, general kernel, list rotation
+hipError_t launch_wp_sched_init(const WpSchedArgs& sa, uint32_t* list_storage, uint32_t n_fresh, hipStream_t stream);
+hipError_t launch_wp_sched_round(const FmIndexDev& fm, const WpArgs& a, const WpSchedArgs& fast, const WpSchedArgs& general, uint32_t n_lanes_fast,
+                                 uint32_t n_lanes_general, hipStream_t stream);
 hipError_t launch_wp_dp_collect(const WpArgs& a, const WpDpItem* items, hipStream_t stream);
 hipError_t launch_wp_stitch(const WpArgs& a, hipStream_t stream);
 hipError_t launch_wp_gather(const WpArgs& a, const uint64_t* dst_off, char* dst, hipStream_t stream);

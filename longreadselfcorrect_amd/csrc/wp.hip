@@ -284,12 +284,14 @@ __global__ __launch_bounds__(64) void wp_begin_kernel(FmIndexDev fm, WpArgs a)
 // extend: persistent lanes over a queue of walks
 // ---------------------------------------------------------------------------------------
 template <bool WIDE>
-__global__ __launch_bounds__(64, 4) void wp_extend_kernel(FmIndexDev fm, WpArgs a)
+__global__ __launch_bounds__(64, 2) void wp_extend_kernel(FmIndexDev fm, WpArgs a)
 {
     using P = typename Lay<WIDE>::pos_t;
     __shared__ __attribute__((aligned(16))) uint32_t mtab[MaskTabSize<WIDE>::value];
     init_mask_table<WIDE>(mtab);
-    const uint32_t lane_id = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t stride = a.lane_stride ? a.lane_stride : 1u;
+    const bool owner = (threadIdx.x % stride) == 0;
+    const uint32_t lane_id = owner ? (blockIdx.x * 64 + threadIdx.x) / stride : 0xFFFFFFFFu;
     Walk<WIDE> W;
     W.sF = strand_consts<P>(fm.strand[LRSC_RBWT]);
     W.sR = strand_consts<P>(fm.strand[LRSC_BWT]);
@@ -298,22 +300,33 @@ __global__ __launch_bounds__(64, 4) void wp_extend_kernel(FmIndexDev fm, WpArgs 
     W.PBcoverage = a.pb_coverage; W.PacBioErrorRate = a.pacbio_error_rate; W.errorRate = 0.25; W.localK = 100;
     W.freqsOfKmerSize = a.freqs_of_kmer_size;
     const WpLaneLayout LL = wp_lane_layout(a.lbytes, a.lane_pathw);
-    uint8_t* lws = a.lane_ws + (uint64_t)lane_id * a.lane_ws_bytes;
+    uint8_t* lws = a.lane_ws + (uint64_t)(owner ? lane_id : 0u) * a.lane_ws_bytes;
     Leaf<P>* const leaf_base = reinterpret_cast<Leaf<P>*>(lws + LL.leaves);
     W.rings = reinterpret_cast<double*>(lws + LL.rings);
     W.results = reinterpret_cast<WalkResultRec*>(lws + LL.results);
     W.paths = reinterpret_cast<uint32_t*>(lws + LL.paths);
     W.pathw = a.lane_pathw;
     W.rpaths = W.paths + (uint64_t)32 * a.lane_pathw;
-    W.n_rank = 0; W.n_blk = 0; W.steps = 0; W.error = 0; W.cyc_setup = 0; W.cyc_loop = 0; W.prof = nullptr; W.profile = false;
+    W.n_rank = 0; W.n_blk = 0; W.steps = 0; W.leaf_steps = 0; W.error = 0; W.cyc_setup = 0; W.cyc_loop = 0; W.prof = nullptr; W.profile = false;
     const uint64_t min_SA = a.pb_coverage > 60 ? (uint64_t)((a.pb_coverage / 60) * 3) : 3;
 
     bool in_walk = false;
     uint32_t si = 0;
     uint64_t steps0 = 0;
+    // single-leaf fast path (walk_device.h): the one leaf of the frontier in registers
+    Leaf<P> L;
+    uint32_t pw = 0;
+    bool fast = false;
+    // profiling (a.prof): per-lane wall ticks inside the step's regions (Walk::tock slots 0-6), 8 = refill, 9 = finish, 10 = whole loop
+    uint64_t pr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t t_refill = 0, t_finish = 0, n_fast = 0;
+    const bool prof = a.prof != nullptr;
+    if(prof) W.prof = pr;
+    const uint64_t t_loop0 = prof ? __builtin_readcyclecounter() : 0;
     if(lane_id < a.n_lanes)
     while(true) {
         if(!in_walk) {
+            const uint64_t tr0 = prof ? __builtin_readcyclecounter() : 0;
             const uint32_t i = atomicAdd(a.queue, 1u);
             if(i >= a.n_list) break;
             if(a.reqs && a.reqs[i].kind != kWpReqFm) continue;
@@ -331,17 +344,29 @@ __global__ __launch_bounds__(64, 4) void wp_extend_kernel(FmIndexDev fm, WpArgs 
             W.minLength = (uint64_t)((0.8 * ((int32_t)s.gap - 20)) + (double)(2 * (uint64_t)s.k));
             W.cur = leaf_base; W.nxt = leaf_base + 32; W.leaf_small = leaf_base;
             W.error = 0;
-            steps0 = W.steps;
+            steps0 = W.steps; W.leaf_steps = 0;
             const P riv[4] = {(P)H->root[0], (P)H->root[1], (P)H->root[2], (P)H->root[3]};
             W.begin_root(riv);
             in_walk = true;
+            fast = false;
+            if(prof) t_refill += __builtin_readcyclecounter() - tr0;
         }
-        if(W.step()) continue;
+        if(!fast && W.can_fast()) { W.enter_fast(L, pw); fast = true; }
+        int r = 2;
+        if(fast) {
+            const uint64_t tq = prof ? __builtin_readcyclecounter() : 0;
+            r = W.step_fast(L, pw);
+            if(r != 1) fast = false;
+            if(prof) { pr[7] += __builtin_readcyclecounter() - tq; if(r == 1) ++n_fast; }
+        }
+        if(r == 2) r = W.step() ? 1 : 0;
+        if(r == 1) continue;
         in_walk = false;
+        const uint64_t tf0 = prof ? __builtin_readcyclecounter() : 0;
         WpSlot& s = a.slots[si];
         uint32_t plen = 0, mi = 0;
         const int code = W.finish(&plen, s.path, &mi);
-        s.code = code; s.path_len = plen; s.match_i = mi; s.steps = (uint32_t)(W.steps - steps0);
+        s.code = code; s.path_len = plen; s.match_i = mi; s.steps = (uint32_t)(W.steps - steps0); s.leaf_steps = W.leaf_steps;
         s.flags |= (uint8_t)kWpFmValid;
         if(code <= 0 && code > LRSC_WALK_ERR_CHILDREN && a.auto_dp && s.next == 0) {
             const uint32_t j = atomicAdd(a.n_dp_items, 1u);
@@ -350,8 +375,280 @@ __global__ __launch_bounds__(64, 4) void wp_extend_kernel(FmIndexDev fm, WpArgs 
                 a.dp_items[j] = d;
             }
         }
+        if(prof) t_finish += __builtin_readcyclecounter() - tf0;
+    }
+    if(prof && lane_id < a.n_lanes) {
+        for(int j = 0; j < 8; ++j) atomicAdd(&a.prof[j], (unsigned long long)pr[j]);
+        atomicAdd(&a.prof[8], (unsigned long long)t_refill);
+        atomicAdd(&a.prof[9], (unsigned long long)t_finish);
+        atomicAdd(&a.prof[10], (unsigned long long)(__builtin_readcyclecounter() - t_loop0));
+        atomicAdd(&a.prof[11], (unsigned long long)W.steps);
+        atomicAdd(&a.prof[12], (unsigned long long)n_fast);
     }
     flush_counters(a.ctr, W.n_rank, W.n_blk);
+}
+
+// ---------------------------------------------------------------------------------------
+// the two-class schedule (wp.h): wp_fast_kernel steps single-leaf frontiers, wp_general_kernel everything else
+// ---------------------------------------------------------------------------------------
+constexpr uint32_t kWpCtxHeader = 64;
+
+// One atomic per wavefront instead of one per lane: the lanes that `want` a ticket of the counter get consecutive ones
+// (a hundred thousand lanes hammering six list counters serialise in the L2 otherwise).  Call with any subset of lanes active.
+__device__ __forceinline__ uint32_t wave_claim(uint32_t* ctr, bool want)
+{
+    const uint64_t m = __ballot(want);
+    if(m == 0) return 0;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t leader = (uint32_t)__builtin_ctzll(m);
+    uint32_t base = 0;
+    if(lane == leader) base = atomicAdd(ctr, (uint32_t)__builtin_popcountll(m));
+    base = __shfl(base, (int)leader, 64);
+    return base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+}
+__device__ __forceinline__ void wp_push(WpSched* S, int which, uint32_t c, bool want = true)
+{
+    const uint32_t k = wave_claim(&S->list[which].n, want);
+    if(want) S->list[which].items[k] = c;
+}
+
+// constants of the Walk object that do not depend on the walk
+template <bool WIDE>
+__device__ __forceinline__ void wp_walk_consts(Walk<WIDE>& W, const FmIndexDev& fm, const WpArgs& a, const uint32_t* mtab)
+{
+    using P = typename Lay<WIDE>::pos_t;
+    W.sF = strand_consts<P>(fm.strand[LRSC_RBWT]);
+    W.sR = strand_consts<P>(fm.strand[LRSC_BWT]);
+    W.fm = &fm; W.mtab = mtab;
+    W.seedSize = a.seed_size; W.minOverlap = a.min_overlap; W.maxLeaves = a.max_leaves;
+    W.PBcoverage = a.pb_coverage; W.PacBioErrorRate = a.pacbio_error_rate; W.errorRate = 0.25; W.localK = 100;
+    W.freqsOfKmerSize = a.freqs_of_kmer_size;
+    W.n_rank = 0; W.n_blk = 0; W.steps = 0; W.leaf_steps = 0; W.error = 0; W.cyc_setup = 0; W.cyc_loop = 0; W.prof = nullptr; W.profile = false;
+    W.n_nxt = 0; W.ended = false;
+}
+
+// the per-walk part: tables of the prepared state, geometry, the context's dynamic regions
+template <bool WIDE>
+__device__ __forceinline__ void wp_walk_bind(Walk<WIDE>& W, const WpArgs& a, const WpSlot& s, uint8_t* dyn, uint32_t pathw, const WpStatic* H)
+{
+    using P = typename Lay<WIDE>::pos_t;
+    wp_bind_static<WIDE>(W, a, s);
+    W.n9f = H->n9f; W.n9r = H->n9r; W.tmask0 = H->tmask0; W.tmask1 = H->tmask1;
+    W.maxOverlap = (uint32_t)s.k + 2;
+    W.min_SA_threshold = a.pb_coverage > 60 ? (uint64_t)((a.pb_coverage / 60) * 3) : 3;
+    // .cpp:55-58,78-79: double expressions truncated to size_t
+    if((int32_t)s.gap > 100) W.maxIndelSize = (uint64_t)((int32_t)s.gap * 0.2); else W.maxIndelSize = 20;
+    W.maxLength = (uint64_t)((1.2 * ((int32_t)s.gap + 10)) + (double)(2 * (uint64_t)s.k));
+    W.minLength = (uint64_t)((0.8 * ((int32_t)s.gap - 20)) + (double)(2 * (uint64_t)s.k));
+    const WpLaneLayout LL = wp_lane_layout(a.lbytes, pathw);
+    W.leaf_small = reinterpret_cast<Leaf<P>*>(dyn + LL.leaves);
+    W.rings = reinterpret_cast<double*>(dyn + LL.rings);
+    W.results = reinterpret_cast<WalkResultRec*>(dyn + LL.results);
+    W.paths = reinterpret_cast<uint32_t*>(dyn + LL.paths);
+    W.pathw = pathw;
+    W.rpaths = W.paths + (uint64_t)32 * pathw;
+}
+
+template <bool WIDE>
+__device__ __forceinline__ void wp_ctx_load(Walk<WIDE>& W, const WpCtx& C)
+{
+    W.currentLength = C.currentLength; W.currentKmerSize = C.currentKmerSize;
+    W.n_cur = C.n_cur; W.n_results = C.n_results; W.n_nxt = 0;
+    W.ring_free = C.ring_free; W.path_free = C.path_free;
+    W.steps = C.steps; W.leaf_steps = C.pad; W.ended = C.ended != 0; W.error = C.error;
+    if(C.cur_is_small) { W.cur = W.leaf_small; W.nxt = W.leaf_small + 32; }
+    else { W.cur = W.leaf_small + 32; W.nxt = W.leaf_small; }
+}
+template <bool WIDE>
+__device__ __forceinline__ void wp_ctx_save(const Walk<WIDE>& W, WpCtx& C, uint32_t slot)
+{
+    C.slot = slot;
+    C.currentLength = (uint32_t)W.currentLength; C.currentKmerSize = (uint32_t)W.currentKmerSize;
+    C.n_cur = W.n_cur; C.n_results = W.n_results;
+    C.ring_free = W.ring_free; C.path_free = W.path_free;
+    C.steps = (uint32_t)W.steps; C.pad = W.leaf_steps; C.cur_is_small = W.cur == W.leaf_small ? 1u : 0u; C.ended = W.ended ? 1u : 0u; C.error = W.error;
+}
+
+// extendOverlap is over: findTheBestPath / the failure code, the slot's result, the DP stage's work item
+template <bool WIDE>
+__device__ __noinline__ void wp_walk_finish(Walk<WIDE>& W, const WpArgs& a, uint32_t si)
+{
+    WpSlot& s = a.slots[si];
+    uint32_t plen = 0, mi = 0;
+    const int code = W.finish(&plen, s.path, &mi);
+    s.code = code; s.path_len = plen; s.match_i = mi; s.steps = (uint32_t)W.steps; s.leaf_steps = W.leaf_steps;
+    s.flags |= (uint8_t)kWpFmValid;
+    if(code <= 0 && code > LRSC_WALK_ERR_CHILDREN && a.auto_dp && s.next == 0) {
+        const uint32_t j = atomicAdd(a.n_dp_items, 1u);
+        if(j < a.dp_items_cap) {
+            WpDpItem d; d.q = (uint64_t)s.dpq; d.slot = si; d.lq = s.dp_lq; d.k = s.dp_k; d.total_freq = s.dp_total_freq;
+            a.dp_items[j] = d;
+        }
+    }
+}
+
+template <bool WIDE>
+__global__ __launch_bounds__(64, 2) void wp_fast_kernel(FmIndexDev fm, WpArgs a, WpSchedArgs sa)
+{
+    using P = typename Lay<WIDE>::pos_t;
+    __shared__ __attribute__((aligned(16))) uint32_t mtab[MaskTabSize<WIDE>::value];
+    init_mask_table<WIDE>(mtab);
+    WpSched* S = sa.sched;
+    const uint32_t odd = S->round & 1u;
+    const int Fin = odd ? kWpFastB : kWpFastA, Fout = odd ? kWpFastA : kWpFastB;
+    const int Gin = odd ? kWpGenB : kWpGenA;
+    const int FRin = odd ? kWpFreeB : kWpFreeA, FRout = odd ? kWpFreeA : kWpFreeB;
+    const uint32_t n_fin = S->list[Fin].n, n_free = S->list[FRin].n, n_fresh = S->n_fresh;
+    Walk<WIDE> W;
+    wp_walk_consts<WIDE>(W, fm, a, mtab);
+    Leaf<P> L;
+    uint32_t pw = 0;
+    bool have = false;
+    uint32_t c = 0, si = 0, budget = 0;
+    while(true) {
+        if(!have) {
+            // lanes between walks wait for company: pulling a walk stalls the stepping lanes of the wavefront
+            const uint32_t n_all = (uint32_t)__builtin_popcountll(__ballot(true));
+            const uint32_t n_idle = (uint32_t)__builtin_popcountll(__ballot(!have));
+            if(n_idle * 100u < n_all * sa.quorum_pct) continue;
+            bool fresh = false;
+            // resumed walks first, then fresh walks onto free contexts
+            const bool fin_open = S->list[Fin].cursor < n_fin;           // stale reads only cost an extra claim
+            uint32_t i = fin_open ? wave_claim(&S->list[Fin].cursor, true) : n_fin;
+            bool got = i < n_fin;
+            if(got) c = S->list[Fin].items[i];
+            {
+                const uint32_t j = wave_claim(&S->list[FRin].cursor, !got);
+                const bool got_ctx = !got && j < n_free;
+                if(got_ctx) c = S->list[FRin].items[j];
+                const uint32_t f = wave_claim(&S->fresh_cursor, got_ctx);
+                bool got_fresh = got_ctx && f < n_fresh;
+                // an entry that is not a walk to run (a DP request of a later round, a slot with a bad geometry) is done at once
+                bool skip = false;
+                if(got_fresh) {
+                    si = sa.fresh[f];
+                    skip = (a.reqs && a.reqs[f].kind != kWpReqFm) || (a.slots[si].flags & kWpGeomBad) != 0;
+                }
+                wp_push(S, FRout, c, got_ctx && (!got_fresh || skip));    // the context goes back unused
+                (void)wave_claim(&S->finished, skip);
+                if(skip) continue;
+                if(got_fresh) { fresh = true; got = true; }
+            }
+            if(!got) break;                                               // nothing left for this lane in this launch
+            uint8_t* base = sa.ctx_ws + (uint64_t)c * sa.ctx_bytes;
+            WpCtx& C = *reinterpret_cast<WpCtx*>(base);
+            if(!fresh) si = C.slot;
+            const WpSlot& s = a.slots[si];
+            const WpStatic* H = reinterpret_cast<const WpStatic*>(s.prep);
+            wp_walk_bind<WIDE>(W, a, s, base + kWpCtxHeader, sa.ctx_pathw, H);
+            if(fresh) {
+                W.cur = W.leaf_small; W.nxt = W.leaf_small + 32;
+                W.error = 0; W.steps = 0; W.leaf_steps = 0; W.ended = false;
+                const P riv[4] = {(P)H->root[0], (P)H->root[1], (P)H->root[2], (P)H->root[3]};
+                W.begin_root(riv);
+            } else
+                wp_ctx_load<WIDE>(W, C);
+            W.enter_fast(L, pw);
+            have = true;
+            budget = sa.budget;
+        }
+        const int r = W.step_fast(L, pw);
+        --budget;
+        if(r == 1 && budget != 0) continue;
+        have = false;
+        WpCtx& C = *reinterpret_cast<WpCtx*>(sa.ctx_ws + (uint64_t)c * sa.ctx_bytes);
+        if(r == 1) W.leave_fast(L);
+        if(r != 0) wp_ctx_save<WIDE>(W, C, si);
+        else wp_walk_finish<WIDE>(W, a, si);
+        wp_push(S, Fout, c, r == 1);
+        wp_push(S, Gin, c, r == 2);
+        wp_push(S, FRout, c, r == 0);
+        (void)wave_claim(&S->finished, r == 0);
+    }
+    flush_counters(a.ctr, W.n_rank, W.n_blk);
+}
+
+template <bool WIDE>
+__global__ __launch_bounds__(64, 2) void wp_general_kernel(FmIndexDev fm, WpArgs a, WpSchedArgs sa)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t mtab[MaskTabSize<WIDE>::value];
+    init_mask_table<WIDE>(mtab);
+    WpSched* S = sa.sched;
+    const uint32_t odd = S->round & 1u;
+    const int Fout = odd ? kWpFastA : kWpFastB;
+    const int Gin = odd ? kWpGenB : kWpGenA, Gout = odd ? kWpGenA : kWpGenB;
+    const int FRin = odd ? kWpFreeB : kWpFreeA, FRout = odd ? kWpFreeA : kWpFreeB;
+    // contexts the fast kernel did not hand out stay free
+    {
+        const uint32_t n_free = S->list[FRin].n, cur = S->list[FRin].cursor;
+        const uint32_t first = cur < n_free ? cur : n_free;
+        for(uint32_t i = first + blockIdx.x * 64 + threadIdx.x; i < n_free; i += gridDim.x * 64) wp_push(S, FRout, S->list[FRin].items[i]);
+    }
+    const uint32_t n_gin = S->list[Gin].n;
+    Walk<WIDE> W;
+    wp_walk_consts<WIDE>(W, fm, a, mtab);
+    bool have = false;
+    uint32_t c = 0, si = 0, budget = 0;
+    while(true) {
+        if(!have) {
+            const uint32_t n_all = (uint32_t)__builtin_popcountll(__ballot(true));
+            const uint32_t n_idle = (uint32_t)__builtin_popcountll(__ballot(!have));
+            if(n_idle * 100u < n_all * sa.quorum_pct) continue;
+            const uint32_t i = wave_claim(&S->list[Gin].cursor, true);
+            if(i >= n_gin) break;
+            c = S->list[Gin].items[i];
+            uint8_t* base = sa.ctx_ws + (uint64_t)c * sa.ctx_bytes;
+            const WpCtx& C = *reinterpret_cast<const WpCtx*>(base);
+            si = C.slot;
+            const WpSlot& s = a.slots[si];
+            wp_walk_bind<WIDE>(W, a, s, base + kWpCtxHeader, sa.ctx_pathw, reinterpret_cast<const WpStatic*>(s.prep));
+            wp_ctx_load<WIDE>(W, C);
+            have = true;
+            budget = sa.budget;
+        }
+        budget = budget > W.n_cur ? budget - W.n_cur : 0u;            // the budget counts leaf-steps: a wide frontier hands back sooner
+        const bool go = W.step();
+        if(go && !W.can_fast() && budget != 0) continue;
+        have = false;
+        WpCtx& C = *reinterpret_cast<WpCtx*>(sa.ctx_ws + (uint64_t)c * sa.ctx_bytes);
+        if(!go) wp_walk_finish<WIDE>(W, a, si);
+        else wp_ctx_save<WIDE>(W, C, si);
+        const bool to_fast = go && W.can_fast();
+        wp_push(S, FRout, c, !go);
+        (void)wave_claim(&S->finished, !go);
+        wp_push(S, Fout, c, to_fast);
+        wp_push(S, Gout, c, go && !to_fast);
+    }
+    flush_counters(a.ctr, W.n_rank, W.n_blk);
+}
+
+// list rotation between the launches of a round: phase 0 after the fast kernel, phase 1 after the general kernel
+__global__ void wp_sched_advance_kernel(WpSched* S, int phase)
+{
+    const uint32_t odd = S->round & 1u;
+    if(phase == 0) {
+        WpList& F = S->list[odd ? kWpFastB : kWpFastA];
+        F.n = 0; F.cursor = 0;
+    } else {
+        WpList& G = S->list[odd ? kWpGenB : kWpGenA];
+        G.n = 0; G.cursor = 0;
+        WpList& R = S->list[odd ? kWpFreeB : kWpFreeA];
+        R.n = 0; R.cursor = 0;
+        S->round += 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void wp_sched_init_kernel(WpSchedArgs sa, uint32_t* storage, uint32_t n_fresh)
+{
+    WpSched* S = sa.sched;
+    const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
+    if(gid == 0) {
+        for(int l = 0; l < kWpLists; ++l) { S->list[l].items = storage + (uint64_t)l * sa.n_ctx; S->list[l].n = 0; S->list[l].cursor = 0; }
+        S->list[kWpFreeA].n = sa.n_ctx;
+        S->fresh_cursor = 0; S->n_fresh = n_fresh; S->finished = 0; S->round = 0;
+    }
+    uint32_t* free_a = storage + (uint64_t)kWpFreeA * sa.n_ctx;
+    for(uint32_t i = gid; i < sa.n_ctx; i += gridDim.x * 256) free_a[i] = i;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -618,9 +915,29 @@ hipError_t launch_wp_begin(const FmIndexDev& fm, const WpArgs& a, hipStream_t st
 hipError_t launch_wp_extend(const FmIndexDev& fm, const WpArgs& a, hipStream_t stream)
 {
     if(a.n_list == 0 || a.n_lanes == 0) return hipSuccess;
-    const unsigned nb = (a.n_lanes + 63) / 64;
+    const unsigned stride = a.lane_stride ? a.lane_stride : 1u;
+    const unsigned nb = (unsigned)(((uint64_t)a.n_lanes * stride + 63) / 64);
     if(fm.wide) hipLaunchKernelGGL(wp_extend_kernel<true>, dim3(nb), dim3(64), 0, stream, fm, a);
     else        hipLaunchKernelGGL(wp_extend_kernel<false>, dim3(nb), dim3(64), 0, stream, fm, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_wp_sched_init(const WpSchedArgs& sa, uint32_t* list_storage, uint32_t n_fresh, hipStream_t stream)
+{
+    hipLaunchKernelGGL(wp_sched_init_kernel, dim3(256), dim3(256), 0, stream, sa, list_storage, n_fresh);
+    return hipGetLastError();
+}
+
+hipError_t launch_wp_sched_round(const FmIndexDev& fm, const WpArgs& a, const WpSchedArgs& sa, const WpSchedArgs& sg, uint32_t n_lanes_fast,
+                                 uint32_t n_lanes_general, hipStream_t stream)
+{
+    const unsigned nf = (n_lanes_fast + 63) / 64, ng = (n_lanes_general + 63) / 64;
+    if(fm.wide) hipLaunchKernelGGL(wp_fast_kernel<true>, dim3(nf), dim3(64), 0, stream, fm, a, sa);
+    else        hipLaunchKernelGGL(wp_fast_kernel<false>, dim3(nf), dim3(64), 0, stream, fm, a, sa);
+    hipLaunchKernelGGL(wp_sched_advance_kernel, dim3(1), dim3(1), 0, stream, sa.sched, 0);
+    if(fm.wide) hipLaunchKernelGGL(wp_general_kernel<true>, dim3(ng), dim3(64), 0, stream, fm, a, sg);
+    else        hipLaunchKernelGGL(wp_general_kernel<false>, dim3(ng), dim3(64), 0, stream, fm, a, sg);
+    hipLaunchKernelGGL(wp_sched_advance_kernel, dim3(1), dim3(1), 0, stream, sa.sched, 1);
     return hipGetLastError();
 }
 

@@ -376,6 +376,7 @@ struct OrcRun {
     std::string correct_fa, discard_fa, stats;
     std::vector<int64_t> counters;     // per read: 10 counters (PacBioSelfCorrectionResult order) + merge flag
     std::vector<int32_t> walks;        // flat: read, srcStart, trgStart, code, via
+    std::vector<int32_t> walk_work;    // flat, same order: gap, extension steps, leaf expansions
     uint64_t walk_stats[3] = {0, 0, 0};
     uint64_t spec[6] = {0, 0, 0, 0, 0, 0};
 };
@@ -415,6 +416,8 @@ void* orc_correct_reads(void* bwt, void* rbwt, const lrsc_params* p, const char*
         for(const auto& w : res.walks) {
             const int32_t v[5] = {(int32_t)r, w.srcStartPos, w.trgStartPos, w.code, w.via};
             run->walks.insert(run->walks.end(), v, v + 5);
+            const int32_t x[3] = {w.gap, w.steps, w.leaf_expansions};
+            run->walk_work.insert(run->walk_work.end(), x, x + 3);
         }
         run->walk_stats[0] += res.walk_stats.steps;
         run->walk_stats[1] += res.walk_stats.leaf_expansions;
@@ -446,6 +449,12 @@ uint64_t orc_run_walks(void* h, int32_t* out, uint64_t cap)
     const OrcRun* r = static_cast<OrcRun*>(h);
     if(out && cap >= r->walks.size()) std::memcpy(out, r->walks.data(), r->walks.size() * 4);
     return r->walks.size();
+}
+uint64_t orc_run_walk_work(void* h, int32_t* out, uint64_t cap)
+{
+    const OrcRun* r = static_cast<OrcRun*>(h);
+    if(out && cap >= r->walk_work.size()) std::memcpy(out, r->walk_work.data(), r->walk_work.size() * 4);
+    return r->walk_work.size();
 }
 void orc_run_walk_stats(void* h, uint64_t* out3)
 {

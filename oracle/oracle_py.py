@@ -312,6 +312,16 @@ class OracleRun:
         return out.reshape(-1, 5)          # read, srcStart, trgStart, code, via(0 FM, 1 DP, 2 raw/split)
 
     @property
+    def walk_work(self) -> np.ndarray:
+        f = self.o.lib.orc_run_walk_work
+        f.restype = C.c_uint64
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        n = f(self.h, None, 0)
+        out = np.zeros(n, dtype=np.int32)
+        f(self.h, _p(out), n)
+        return out.reshape(-1, 3)          # gap, extension steps, leaf expansions (same order as walks)
+
+    @property
     def walk_stats(self):
         out = np.zeros(3, dtype=np.uint64)
         self.o.lib.orc_run_walk_stats(self.h, _p(out))

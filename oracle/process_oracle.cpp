@@ -59,6 +59,8 @@ void SelfCorrectionProcess::initCorrect(std::string& readSeq, const SeedFeature:
         SeedFeature& source = pieceVec.back();
         std::string mergedSeq;
         const int walkSrcStart = source.seedStartPos;
+        const uint64_t steps_before = result.walk_stats.steps, exp_before = result.walk_stats.leaf_expansions;
+        const int gap_now = iterTarget->seedStartPos - source.seedEndPos - 1;
         {   // instrumentation only (no effect on the result): predicted vs actual source k-mer of this walk
             const SeedFeature& target = *iterTarget;
             auto ksize = [&](int endBest, bool srcRepeat, int srcLen) {
@@ -80,7 +82,7 @@ void SelfCorrectionProcess::initCorrect(std::string& readSeq, const SeedFeature:
             firstFMExtensionType = (next == 0 ? isFMExtensionSuccess : firstFMExtensionType);
             if(isFMExtensionSuccess > 0) {
                 result.totalWalkNum++;
-                result.walks.push_back({walkSrcStart, target.seedStartPos, isFMExtensionSuccess, 0});
+                result.walks.push_back({walkSrcStart, target.seedStartPos, isFMExtensionSuccess, 0, gap_now, (int)(result.walk_stats.steps - steps_before), (int)(result.walk_stats.leaf_expansions - exp_before)});
                 source.append(mergedSeq, target);
                 iterTarget += next;
                 case_number += next;
@@ -102,7 +104,7 @@ void SelfCorrectionProcess::initCorrect(std::string& readSeq, const SeedFeature:
 
             result.totalWalkNum++;
             bool isMSAlignmentSuccess = correctByMSAlignment(source, target, readSeq, mergedSeq, result);
-            result.walks.push_back({walkSrcStart, target.seedStartPos, firstFMExtensionType, isMSAlignmentSuccess ? 1 : 2});
+            result.walks.push_back({walkSrcStart, target.seedStartPos, firstFMExtensionType, isMSAlignmentSuccess ? 1 : 2, gap_now, (int)(result.walk_stats.steps - steps_before), (int)(result.walk_stats.leaf_expansions - exp_before)});
             if(isMSAlignmentSuccess)
                 source.append(mergedSeq, target);
             else {

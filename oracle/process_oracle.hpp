@@ -35,6 +35,7 @@ struct WalkRecord {                  // one seed-pair walk (what --debugseed's e
     int srcStartPos, trgStartPos;
     int code;                        // extendOverlap return: 1, -1, -2, -3
     int via;                         // 0 = FM-extend, 1 = DP fallback, 2 = raw copy / split
+    int gap = 0, steps = 0, leaf_expansions = 0;   // of the FM attempts towards this target (test visibility)
 };
 
 struct CorrectionResult {            // PacBioSelfCorrectionProcess.h:58-94
