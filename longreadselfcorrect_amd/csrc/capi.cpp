@@ -23,7 +23,6 @@
 #include "kernels.h"
 #include "extend.h"
 #include "correct_dev.h"
-#include "correct_layout.h"
 #include "dp_dev.h"
 #include "wp.h"
 #include "introsort_emul.h"
@@ -1420,26 +1419,13 @@ struct DpStage {
 // device, which serialises contexts that correct sub-batches concurrently on one GPU and costs every call of a loop.
 struct CorrectScratch {
     DevBuf<ReadPlan> d_plan;
-    DevBuf<ReadWork> d_work;
-    DevBuf<ReadOut> d_out;
-    DevBuf<uint32_t> d_order, d_pieces, d_queue, d_dp_index, d_parked, d_yielded, d_trace;
-    DevBuf<uint8_t> d_ws, d_codes_out;
+    DevBuf<uint32_t> d_pieces;
+    DevBuf<uint8_t> d_codes_out;
     DevBuf<uint64_t> d_dst_off;
     DevBuf<char> d_dst;
     DevBuf<double> d_freqs;
-    DevBuf<CorrectArgs> d_args;
-    DevBuf<FmIndexDev> d_fm;
-    DevBuf<unsigned long long> d_prof;
     DpStage stage;
     struct WpScratch* wp = nullptr;          // buffers of the walk-parallel flow
-    hipStream_t ystream = nullptr;
-    hipEvent_t y0 = nullptr, y1 = nullptr;
-    ~CorrectScratch()
-    {
-        if(ystream) { (void)hipStreamSynchronize(ystream); (void)hipStreamDestroy(ystream); }
-        if(y0) (void)hipEventDestroy(y0);
-        if(y1) (void)hipEventDestroy(y1);
-    }
 };
 struct WpScratch;
 static void free_wp_scratch(WpScratch* w);
@@ -1530,11 +1516,11 @@ static int batch_correct_wp(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result* res,
     HIP_TRY(hipMemcpyAsync(cs.d_freqs.p, freqs, sizeof(freqs), hipMemcpyHostToDevice, ctx->stream));
 
     // ---- per-read bounds (longest gap / query any walk of the read can have) -> output slots, skipped reads -----------
-    CorrectArgs pa{};
+    WpArgs pa{};
     pa.codes = b->d_codes; pa.read_off = b->d_off; pa.seeds = b->d_seeds; pa.seed_count = b->d_seed_count;
-    pa.n_reads = n; pa.min_k = b->min_k; pa.next_target = p.next_target; pa.plan = cs.d_plan.p;
-    hipError_t e = launch_correct_plan(pa, ctx->stream);
-    if(e != hipSuccess) return hip_fail(e, "correct_plan");
+    pa.n_reads = n; pa.min_k = b->min_k; pa.next_target = p.next_target;
+    hipError_t e = launch_wp_bounds(pa, cs.d_plan.p, ctx->stream);
+    if(e != hipSuccess) return hip_fail(e, "wp_bounds");
     std::vector<ReadPlan> plan(n);
     std::vector<uint32_t> seed_count(n);
     std::vector<uint64_t> off(n + 1);
@@ -1607,7 +1593,7 @@ static int batch_correct_wp(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result* res,
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
     uint32_t max_lanes = (uint32_t)cus * 4u * 4u * 64u;              // 4 wavefronts per SIMD (128 VGPRs)
     if(const char* ev = std::getenv("LRSC_WP_LANES")) max_lanes = (uint32_t)std::max(64, std::atoi(ev));
-    uint64_t prep_budget = 32ull << 30, lane_budget = 32ull << 30;
+    uint64_t prep_budget = 24ull << 30, lane_budget = 32ull << 30;
     if(const char* ev = std::getenv("LRSC_WP_PREP_MB")) prep_budget = std::max<uint64_t>(1, (uint64_t)std::atoll(ev)) << 20;
     if(const char* ev = std::getenv("LRSC_WP_LANE_MB")) lane_budget = std::max<uint64_t>(1, (uint64_t)std::atoll(ev)) << 20;
 
@@ -1619,12 +1605,15 @@ static int batch_correct_wp(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result* res,
     }
     if(!ws.ev_ready) HIP_TRY(hipEventCreateWithFlags(&ws.ev_ready, hipEventDisableTiming));
 
+    uint32_t iso_div = 1;
+    if(const char* ev = std::getenv("LRSC_WP_ISO_DIV")) iso_div = (uint32_t)std::max(1, std::atoi(ev));
     // One launch of the one-kernel form (wp_extend_kernel: every lane runs both kinds of step) over `count` list entries;
     // stride 64 = one walk per wavefront
     auto extend_range = [&](WpArgs x, const uint32_t* list, const WpRequest* reqs, uint32_t count, uint32_t pathw, hipStream_t st, int which, uint32_t stride) -> hipError_t {
         if(count == 0) return hipSuccess;
         const WpLaneLayout LL = wp_lane_layout(lbytes, pathw);
-        uint64_t lanes = std::min<uint64_t>(stride == 1 ? (((uint64_t)count + 63) & ~63ull) : count, max_lanes / stride);
+        // isolated walks (stride > 1) take at most a quarter of the wavefront slots when they run beside the bulk
+        uint64_t lanes = std::min<uint64_t>(stride == 1 ? (((uint64_t)count + 63) & ~63ull) : count, which ? max_lanes / stride / iso_div : max_lanes / stride);
         lanes = std::max<uint64_t>(1, std::min<uint64_t>(lanes, (lane_budget / (which ? 4 : 1)) / LL.total));
         if(stride == 1) lanes = std::max<uint64_t>(64, lanes & ~63ull);
         DevBuf<uint8_t>& buf = which ? ws.d_lane_side : ws.d_lane;
@@ -1729,7 +1718,7 @@ static int batch_correct_wp(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result* res,
         uint64_t est = 0;
         while(r1 < n) {
             const uint64_t ns = work[r1].n_seeds;
-            const uint64_t need = ns >= 2 ? 48 * (off[r1 + 1] - off[r1] + 64 * ns) + ns * 8192 : 0;
+            const uint64_t need = ns >= 2 ? 55 * (off[r1 + 1] - off[r1]) + ns * 4400 : 0;     // 39 B per query character + 16 B per target character + 3.3 KB per walk
             if(r1 > r0 && est + need > prep_budget) break;
             est += need;
             ++r1;
@@ -1815,7 +1804,7 @@ static int batch_correct_wp(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result* res,
                 if(e2 == hipSuccess) e2 = launch_wp_begin(ctx->fm, a, ctx->stream);
                 if(e2 != hipSuccess) return e2;
                 if(!use_sched) {
-                    if(round != 0) return extend_range(a, a.list, a.reqs, n_ent, std::max(stats[2], 1u), ctx->stream, 0, n_ent < 4096 ? 64u : 1u);
+                    if(round != 0) return extend_range(a, a.list, a.reqs, n_ent, std::max(stats[2], 1u), ctx->stream, 0, n_ent <= 16384 ? 64u : n_ent <= 65536 ? 16u : 1u);
                     // the walks across long gaps (the first n_mid of the launch order): one per wavefront, beside the bulk
                     e2 = side_begin();
                     if(e2 == hipSuccess) e2 = extend_range(a, ext_list, nullptr, n_mid, stats[2], ws.side[0], 1, 64);
@@ -1897,6 +1886,13 @@ static int batch_correct_wp(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result* res,
                 std::fprintf(stderr, "[lrsc] wp walks of the range: %u, %llu steps, %llu leaf-steps; hardest (gap, k, steps, leaf-steps, code):", n_range, tot_steps, tot);
                 for(uint32_t i = 0; i < std::min<uint32_t>(n_range, 12); ++i)
                     std::fprintf(stderr, " (%u,%u,%u,%u,%d)", hs[ord[i]].gap, (unsigned)hs[ord[i]].k, hs[ord[i]].steps, hs[ord[i]].leaf_steps, hs[ord[i]].code);
+                {
+                    unsigned long long hist[34] = {0}, wsteps[34] = {0};
+                    for(const WpSlot& q : hs) { const unsigned m = std::min<unsigned>(q.max_front, 33); hist[m]++; wsteps[m] += q.leaf_steps; }
+                    std::fprintf(stderr, "; walks (and their leaf-steps in %%) by widest frontier:");
+                    unsigned long long cw = 0, cs = 0;
+                    for(unsigned m = 1; m < 34; ++m) { cw += hist[m]; cs += wsteps[m]; if(hist[m]) std::fprintf(stderr, " %u:%.2f%%(%.1f%%)", m, 100.0 * hist[m] / n_range, 100.0 * wsteps[m] / std::max(tot, 1ull)); }
+                }
                 const uint32_t qs[] = {n_range / 2, n_range / 10, n_range / 100, n_range / 1000, n_range / 10000};
                 std::fprintf(stderr, "; leaf-steps at the median / top 10%% / 1%% / 0.1%% / 0.01%%: %u %u %u %u %u\n", hs[ord[qs[0]]].leaf_steps, hs[ord[qs[1]]].leaf_steps,
                              hs[ord[qs[2]]].leaf_steps, hs[ord[qs[3]]].leaf_steps, hs[ord[qs[4]]].leaf_steps);
@@ -1978,9 +1974,8 @@ static int batch_correct_wp(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result* res,
 // ---------------------------------------------------------------------------------------
 // the whole per-read path on the device
 // ---------------------------------------------------------------------------------------
-// PacBioSelfCorrectionProcess::process for a resident batch: seeds (if not found yet), a plan kernel that
-// bounds every read's walks, the persistent correction kernel (correct_dev.hip) and a gather of the
-// corrected strings.  The host only sizes buffers and copies results.
+// PacBioSelfCorrectionProcess::process for a resident batch: seeds (if not found yet), then the walk-parallel flow
+// (batch_correct_wp above: wp.hip) and a gather of the corrected strings.  The host only sizes buffers and copies results.
 extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result* res, uint64_t* piece_off, uint64_t piece_cap,
                                   char* out, uint64_t out_cap, uint64_t* n_pieces_out, uint64_t* out_used)
 {
@@ -1998,375 +1993,7 @@ extern "C" int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result
         const int st = lrsc_batch_find_seeds(ctx, b);
         if(st != LRSC_OK) return st;
     }
-    {
-        // default: the walk-parallel flow (wp.hip).  LRSC_CORRECT_FLOW=chain keeps the lane-per-read chain kernel of rounds 1-2.
-        const char* flow = std::getenv("LRSC_CORRECT_FLOW");
-        if(!(flow && std::strcmp(flow, "chain") == 0)) return batch_correct_wp(ctx, b, res, piece_off, piece_cap, out, out_cap, n_pieces_out, out_used);
-    }
-    const bool wide = ctx->fm.wide != 0;
-    const size_t psz = wide ? 8 : 4;
-    const size_t lbytes = leaf_bytes(wide);
-
-    double freqs[101];
-    for(int i = 0; i <= 100; ++i) freqs[i] = 0;
-    for(int i = p.min_kmer_len; i <= 100; i++) freqs[i] = pow(1 - p.error_rate, i) * (size_t)p.pb_coverage;
-
-    // ---- plan: per-read walk bounds from the device-resident seeds ---------------------------------------
-    if(!ctx->cs) ctx->cs = new(std::nothrow) CorrectScratch();
-    if(!ctx->cs) return fail(LRSC_ERR_NOMEM, "correct scratch");
-    CorrectScratch& cs = *ctx->cs;
-    DevBuf<ReadPlan>& d_plan = cs.d_plan;
-    DevBuf<ReadWork>& d_work = cs.d_work;
-    DevBuf<ReadOut>& d_out = cs.d_out;
-    DevBuf<uint32_t>&d_order = cs.d_order, &d_pieces = cs.d_pieces;
-    DevBuf<uint8_t>&d_ws = cs.d_ws, &d_codes_out = cs.d_codes_out;
-    DevBuf<uint64_t>& d_dst_off = cs.d_dst_off;
-    DevBuf<char>& d_dst = cs.d_dst;
-    DevBuf<double>& d_freqs = cs.d_freqs;
-    HIP_TRY(d_plan.reserve(n));
-    HIP_TRY(d_work.reserve(n));
-    HIP_TRY(d_out.reserve(n));
-    HIP_TRY(d_order.reserve(n));
-    HIP_TRY(d_freqs.reserve(101));
-    HIP_TRY(hipMemcpyAsync(d_freqs.p, freqs, sizeof(freqs), hipMemcpyHostToDevice, ctx->stream));
-
-    CorrectArgs a{};
-    a.codes = b->d_codes; a.read_off = b->d_off; a.seeds = b->d_seeds; a.seed_count = b->d_seed_count;
-    a.n_reads = n; a.min_k = b->min_k;
-    if(b->debug_flags & LRSC_DEBUG_WALKS) {
-        if(!b->d_walk_log) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_walk_log), b->seed_cap));
-        HIP_TRY(hipMemsetAsync(b->d_walk_log, 0, b->seed_cap, ctx->stream));
-        a.walk_log = b->d_walk_log;
-        b->walk_log_done = false;
-    }
-    a.plan = d_plan.p; a.out = d_out.p; a.work = d_work.p; a.order = d_order.p;
-    a.seed_size = (uint32_t)p.idmer_len; a.min_overlap = (uint32_t)p.min_kmer_len; a.max_leaves = (uint32_t)p.max_leaves;
-    a.start_kmer_len = p.start_kmer_len; a.next_target = p.next_target; a.split = p.split; a.no_dp = p.no_dp;
-    a.pb_coverage = (uint64_t)p.pb_coverage; a.pacbio_error_rate = p.error_rate;
-    a.freqs_of_kmer_size = d_freqs.p;
-    a.ctr = ctx->d_ctr;
-    // the kernel holds 2 wavefronts per SIMD (216 VGPRs): spread the reads over all of them before doubling up lanes
-    {
-        int cus = 256;
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
-        a.occupancy = 4;
-        if(const char* e = std::getenv("LRSC_CORRECT_OCC")) a.occupancy = std::atoi(e) >= 4 ? 4u : 2u;   // 8 (64 VGPRs) spills too much: 38 s vs 21 s at 100k reads
-        {
-            const char* ke = std::getenv("LRSC_CORRECT_KERNEL");
-            if(ke && std::strcmp(ke, "sm") == 0) a.occupancy = 1;     // the state-machine kernel keeps its per-lane state in LDS: one wavefront per SIMD
-        }
-        const uint32_t resident = (uint32_t)cus * 4u * a.occupancy;
-        a.reads_per_wave = 4;
-        while(a.reads_per_wave < 64 && (n + a.reads_per_wave - 1) / a.reads_per_wave > resident) a.reads_per_wave *= 2;
-    }
-    int rpw_forced = 0;
-    if(const char* e = std::getenv("LRSC_READS_PER_WAVE")) {
-        const int v = std::atoi(e);
-        if(v >= 1 && v <= 64 && (v & (v - 1)) == 0) { a.reads_per_wave = (uint32_t)v; rpw_forced = v; }
-    }
-    // later launches carry fewer reads: spread them over the wavefront slots again
-    auto rpw_for = [&](uint32_t count) -> uint32_t {
-        if(rpw_forced) return (uint32_t)rpw_forced;
-        int cus = 256;
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
-        const uint32_t resident = (uint32_t)cus * 4u * a.occupancy;
-        uint32_t r = 4;
-        while(r < 64 && (count + r - 1) / r > resident) r *= 2;
-        return r;
-    };
-    hipError_t e = launch_correct_plan(a, ctx->stream);
-    if(e != hipSuccess) return hip_fail(e, "correct_plan");
-    std::vector<ReadPlan> plan(n);
-    std::vector<uint32_t> seed_count(n);
-    std::vector<uint64_t> off(n + 1);
-    HIP_TRY(hipMemcpyAsync(plan.data(), d_plan.p, (size_t)n * sizeof(ReadPlan), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(seed_count.data(), b->d_seed_count, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(off.data(), b->d_off, (size_t)(n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-
-    std::vector<ReadWork> work(n);
-    std::vector<int> skipped(n, 0);
-    uint64_t ws_total = 0, out_total = 0, piece_total = 0;
-    for(uint32_t r = 0; r < n; ++r) {
-        ReadWork& w = work[r];
-        std::memset(&w, 0, sizeof(w));
-        const uint64_t rlen = off[r + 1] - off[r];
-        const uint32_t ns = seed_count[r];
-        w.out_off = out_total; w.piece_off = piece_total; w.ws_off = ws_total;
-        if(ns < 2) continue;                                          // nothing to correct: the read is discarded
-        const char* lerr = nullptr;
-        int lcode = 0;
-        const size_t o = layout_read_work(w, rlen, ns, plan[r], p.no_dp != 0, p.split != 0, (uint32_t)p.idmer_len, psz, lbytes, &lerr, &lcode);
-        if(lerr) {
-            // this read alone exceeds a capacity: it is skipped (lq_max = 0 tells the kernels) and reported in its result
-            skipped[r] = lcode;
-            std::memset(&w, 0, sizeof(w));
-            w.out_off = out_total; w.piece_off = piece_total; w.ws_off = ws_total;
-            continue;
-        }
-        out_total += ((uint64_t)w.out_cap + 15) & ~15ull;
-        piece_total += w.piece_cap;
-        ws_total += o;
-    }
-    // launch order: long reads first, similar lengths share a wavefront
-    std::vector<uint32_t> order(n);
-    for(uint32_t i = 0; i < n; ++i) order[i] = i;
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return off[x + 1] - off[x] > off[y + 1] - off[y]; });
-
-    HIP_TRY(d_ws.reserve(std::max<uint64_t>(ws_total, 64)));
-    HIP_TRY(d_codes_out.reserve(std::max<uint64_t>(out_total, 64)));
-    HIP_TRY(d_pieces.reserve(std::max<uint64_t>(piece_total, 1)));
-    HIP_TRY(hipMemcpyAsync(d_work.p, work.data(), (size_t)n * sizeof(ReadWork), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(d_order.p, order.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    a.workspace = d_ws.p; a.out_codes = d_codes_out.p; a.piece_start = d_pieces.p;
-
-    // With the DP fallback on, a read runs at most max_walks walks per launch: a round then lasts about as long as
-    // max_walks walks instead of as long as the luckiest read's failure-free stretch, and parked reads get their answer sooner.
-    // LRSC_CORRECT_QUEUE=k (experimental): launch 1/k of the lanes and let every lane pull reads from a queue.  Off: with 100k
-    // reads it trades resident wavefronts for lane refill and loses (39.9 - 46.6 s vs 32.2 s per Gbase, default flow).
-    DevBuf<uint32_t>& d_queue = cs.d_queue;
-    uint32_t queue_rpl = 0;
-    if(const char* e = std::getenv("LRSC_CORRECT_QUEUE")) queue_rpl = (uint32_t)std::max(0, std::atoi(e));
-    if(queue_rpl) HIP_TRY(d_queue.reserve(1));
-    auto with_queue = [&](CorrectArgs& x) -> hipError_t {
-        if(!queue_rpl) return hipSuccess;
-        x.queue = d_queue.p;
-        x.queue_waves = std::max<uint32_t>(1, (x.n_reads + x.reads_per_wave * queue_rpl - 1) / (x.reads_per_wave * queue_rpl));
-        return hipMemsetAsync(d_queue.p, 0, sizeof(uint32_t), ctx->stream);
-    };
-    // LRSC_CORRECT_KERNEL=sm selects the wavefront-convergent state-machine kernel (correct_sm.hip; bit-identical, measured
-    // 48.6 vs 57.4 Mbases/s at 100k reads on the --nodp flow at the end of round 2: DESIGN.md section 4); the default stays the
-    // lane-per-read kernel of round 1
-    const char* kern_env = std::getenv("LRSC_CORRECT_KERNEL");
-    const bool use_sm = kern_env && std::strcmp(kern_env, "sm") == 0;
-    constexpr uint32_t kArgSlots = 16;
-    DevBuf<CorrectArgs>& d_args = cs.d_args;
-    DevBuf<FmIndexDev>& d_fm = cs.d_fm;
-    uint32_t arg_slot = 0;
-    if(use_sm) {
-        HIP_TRY(d_args.reserve(kArgSlots));
-        HIP_TRY(d_fm.reserve(1));
-        HIP_TRY(hipMemcpyAsync(d_fm.p, &ctx->fm, sizeof(FmIndexDev), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-    }
-    auto launch_correct = [&](const CorrectArgs& x, hipStream_t s) -> hipError_t {
-        if(!use_sm) return launch_correct_reads(ctx->fm, x, s);
-        CorrectArgs* slot = d_args.p + (arg_slot++ % kArgSlots);
-        hipError_t e1 = hipMemcpyAsync(slot, &x, sizeof(CorrectArgs), hipMemcpyHostToDevice, s);
-        if(e1 != hipSuccess) return e1;
-        return launch_correct_sm(d_fm.p, slot, x, ctx->fm.wide != 0, s, ctx->fm);
-    };
-    a.profile = std::getenv("LRSC_CORRECT_PROFILE") ? 1u : 0u;
-    a.setup_quorum_pct = 40;
-    if(const char* e = std::getenv("LRSC_CORRECT_QUORUM")) a.setup_quorum_pct = (uint32_t)std::min(100, std::max(0, std::atoi(e)));
-    a.step_gate_pct = 75;
-    a.slow_gate_sweeps = 12;
-    if(const char* e = std::getenv("LRSC_CORRECT_SLOW_GATE")) a.slow_gate_sweeps = (uint32_t)std::max(1, std::atoi(e));
-    if(const char* e = std::getenv("LRSC_SM_DBG")) a.dbg_flags = (uint32_t)std::atoi(e);
-    if(const char* e = std::getenv("LRSC_CORRECT_GATE")) a.step_gate_pct = (uint32_t)std::min(100, std::max(0, std::atoi(e)));
-    a.max_walks = p.no_dp ? 0u : 64u;
-    a.max_steps = 2000;
-    if(const char* e = std::getenv("LRSC_CORRECT_MAX_WALKS")) a.max_walks = (uint32_t)std::max(0, std::atoi(e));
-    if(const char* e = std::getenv("LRSC_CORRECT_MAX_STEPS")) a.max_steps = (uint32_t)std::max(1, std::atoi(e));
-    // LRSC_SM_TRACE=<file>: debugging aid, per-sweep trace of read LRSC_SM_TRACE_READ (first launch only)
-    DevBuf<uint32_t>& d_trace = cs.d_trace;
-    const char* trace_file = std::getenv("LRSC_SM_TRACE");
-    if(trace_file && use_sm) {
-        a.trace_cap = 14u * 400000u + 1u;
-        HIP_TRY(d_trace.reserve(a.trace_cap));
-        HIP_TRY(hipMemset(d_trace.p, 0, (size_t)a.trace_cap * 4));
-        a.trace = d_trace.p;
-        a.trace_read = std::getenv("LRSC_SM_TRACE_READ") ? (uint32_t)std::atoi(std::getenv("LRSC_SM_TRACE_READ")) : 0u;
-    }
-    // LRSC_SM_PROFILE=1: per-wavefront tick totals of the state-machine kernel's sweep classes (first launch), on stderr
-    DevBuf<unsigned long long>& d_prof = cs.d_prof;
-    uint32_t prof_waves = 0;
-    if(std::getenv("LRSC_SM_PROFILE") && use_sm) {
-        prof_waves = (n + a.reads_per_wave - 1) / a.reads_per_wave;
-        HIP_TRY(d_prof.reserve((size_t)prof_waves * 32));
-        HIP_TRY(hipMemset(d_prof.p, 0, (size_t)prof_waves * 32 * 8));
-        a.prof = d_prof.p;
-    }
-    HIP_TRY(with_queue(a));
-    int st = timed_launch(ctx, LRSC_K_EXTEND, [&]() { return launch_correct(a, ctx->stream); });
-    if(st != LRSC_OK) return st;
-
-    // ---- DP rounds: reads whose FM-extension failed are parked with a correctByMSAlignment request; the DP stage
-    //      answers all of them at once and the kernel resumes just those reads (:129-149) -------------------------------
-    if(a.prof) {
-        std::vector<unsigned long long> pr((size_t)prof_waves * 32);
-        HIP_TRY(hipMemcpy(pr.data(), d_prof.p, pr.size() * 8, hipMemcpyDeviceToHost));
-        double tot[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for(uint32_t w = 0; w < prof_waves; ++w) for(int j = 0; j < 9; ++j) tot[j] += (double)pr[(size_t)w * 32 + j];
-        double blk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for(uint32_t w = 0; w < prof_waves; ++w) for(int j = 0; j < 12; ++j) blk[j] += (double)pr[(size_t)w * 32 + 16 + j];
-        const double all = tot[0] + tot[1] + tot[2] + tot[3] + tot[4];
-        std::fprintf(stderr, "[lrsc] sm kernel, %u waves, ticks per wave %.3g: R-phase %.1f%%; sweeps: begin %.1f%% (%.0f sweeps/wave, %.0f ticks each), "
-                             "between-walks %.1f%% (%.0f, %.0f), step gate open %.1f%% (%.0f, %.0f), light %.1f%% (%.0f, %.0f)\n", prof_waves, all / prof_waves,
-                     100 * tot[0] / all, 100 * tot[1] / all, tot[5] / prof_waves, tot[1] / std::max(tot[5], 1.0), 100 * tot[2] / all, tot[6] / prof_waves,
-                     tot[2] / std::max(tot[6], 1.0), 100 * tot[3] / all, tot[7] / prof_waves, tot[3] / std::max(tot[7], 1.0), 100 * tot[4] / all,
-                     tot[8] / prof_waves, tot[4] / std::max(tot[8], 1.0));
-        std::fprintf(stderr, "[lrsc] sm blocks, M ticks per wave (max lane): results %.0f, ext_eval %.0f, att_done/post %.0f, prune+commit %.0f, step_entry %.0f, "
-                             "walk_end/next %.0f, prep %.0f, begin %.0f, att_entry/leaf/final %.0f\n", blk[0] / prof_waves / 1e6, blk[1] / prof_waves / 1e6,
-                     blk[2] / prof_waves / 1e6, blk[3] / prof_waves / 1e6, blk[4] / prof_waves / 1e6, blk[5] / prof_waves / 1e6, blk[6] / prof_waves / 1e6,
-                     blk[7] / prof_waves / 1e6, blk[8] / prof_waves / 1e6);
-        std::fprintf(stderr, "[lrsc] ext_eval split: parent load %.0f, acceptance ladder %.0f, children %.0f\n", blk[9] / prof_waves / 1e6, blk[10] / prof_waves / 1e6, blk[11] / prof_waves / 1e6);
-        a.prof = nullptr;
-    }
-    if(a.trace) {
-        std::vector<uint32_t> tr(a.trace_cap);
-        HIP_TRY(hipMemcpy(tr.data(), d_trace.p, (size_t)a.trace_cap * 4, hipMemcpyDeviceToHost));
-        if(std::FILE* f = std::fopen(trace_file, "wb")) { std::fwrite(tr.data(), 4, tr[0] ? tr[0] : 1, f); std::fclose(f); }
-        a.trace = nullptr;
-    }
-    std::vector<ReadOut> ro(n);
-    HIP_TRY(hipMemcpy(ro.data(), d_out.p, (size_t)n * sizeof(ReadOut), hipMemcpyDeviceToHost));
-    if(!p.no_dp || a.max_walks != 0) {
-        DpStage& stage = cs.stage;
-        DevBuf<uint32_t>&d_dp_index = cs.d_dp_index, &d_parked = cs.d_parked, &d_yielded = cs.d_yielded;
-        std::vector<uint32_t> parked, yielded, dp_index(n, 0);
-        std::vector<DpRequest> reqs;
-        HIP_TRY(d_dp_index.reserve(n));
-        HIP_TRY(d_parked.reserve(n));
-        HIP_TRY(d_yielded.reserve(n));
-        // LRSC_CORRECT_OVERLAP=1: reads that only used up their step budget go on at once, on a side stream, while the DP stage
-        // answers the parked ones.  Off by default: measured 48.0 s vs 44.1 s per Gbase -- the correction kernel is issue-bound
-        // at full load, two concurrent launches only add a second tail.
-        if(!cs.ystream) HIP_TRY(hipStreamCreateWithFlags(&cs.ystream, hipStreamNonBlocking));
-        if(!cs.y0) HIP_TRY(hipEventCreate(&cs.y0));
-        if(!cs.y1) HIP_TRY(hipEventCreate(&cs.y1));
-        hipStream_t ystream = cs.ystream;
-        hipEvent_t y0 = cs.y0, y1 = cs.y1;
-        struct SideGuard { hipStream_t s; ~SideGuard() { (void)hipStreamSynchronize(s); } } guard{ystream};
-        const bool overlap = std::getenv("LRSC_CORRECT_OVERLAP") != nullptr;
-        for(uint32_t round = 0;; ++round) {
-            parked.clear(); yielded.clear(); reqs.clear();
-            for(uint32_t i = 0; i < n; ++i) {
-                const uint32_t r = order[i];                    // keep the long-reads-first order
-                const ReadOut& o = ro[r];
-                if(o.error != 0 || o.state == kReadDone) continue;
-                if(o.state != kReadParked) { (overlap ? yielded : parked).push_back(r); continue; }
-                parked.push_back(r);
-                DpRequest q;
-                std::memset(&q, 0, sizeof(q));
-                q.q_off = work[r].ws_off + work[r].o_dpq;
-                q.lq = o.dp_lq; q.k = o.dp_k;
-                q.coverage = (uint32_t)p.pb_coverage;
-                q.min_overlap = o.dp_lq / 10;                                            // path.length() / 10
-                // identity / min_call_coverage from the two seeds' maxFixedMerFreq (:225-229)
-                const size_t total = (size_t)o.dp_total_freq;
-                double identity = 0.65;
-                size_t min_call_coverage = 15;
-                identity += (total > 50 ? 0.05 : 0);
-                identity += (total > 100 ? 0.05 : 0);
-                min_call_coverage = total > 50 ? total * 0.4 : min_call_coverage;
-                q.min_identity = identity; q.min_call_coverage = (int32_t)min_call_coverage;
-                dp_index[r] = (uint32_t)reqs.size();
-                reqs.push_back(q);
-            }
-            if(parked.empty() && yielded.empty()) break;
-            if(!yielded.empty()) {
-                HIP_TRY(hipMemcpyAsync(d_yielded.p, yielded.data(), yielded.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ystream));
-                CorrectArgs by = a;
-                by.resume = 1; by.order = d_yielded.p; by.n_reads = (uint32_t)yielded.size();
-                by.reads_per_wave = rpw_for(by.n_reads);
-                by.ctr = nullptr;                               // the main stream's launches own the statistics counters
-                HIP_TRY(hipEventRecord(y0, ystream));
-                hipError_t ey = launch_correct(by, ystream);
-                if(ey != hipSuccess) return hip_fail(ey, "correct_reads (yielded)");
-                HIP_TRY(hipEventRecord(y1, ystream));
-            }
-            if(!parked.empty()) {
-                st = stage.run(ctx, d_ws.p, reqs);
-                if(st != LRSC_OK) return st;
-                HIP_TRY(hipMemcpyAsync(d_dp_index.p, dp_index.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-                HIP_TRY(hipMemcpyAsync(d_parked.p, parked.data(), parked.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-                CorrectArgs b2 = a;
-                b2.resume = 1; b2.order = d_parked.p; b2.n_reads = (uint32_t)parked.size();
-                b2.reads_per_wave = rpw_for(b2.n_reads);
-                b2.dp_index = d_dp_index.p; b2.dp_reqs = stage.d_reqs.p; b2.dp_msa = stage.d_msa.p; b2.dp_cons = stage.d_cons.p;
-                HIP_TRY(with_queue(b2));
-                st = timed_launch(ctx, LRSC_K_EXTEND, [&]() { return launch_correct(b2, ctx->stream); });
-                if(st != LRSC_OK) return st;
-            }
-            if(!yielded.empty()) {
-                HIP_TRY(hipEventSynchronize(y1));
-                float ms = 0.f;
-                HIP_TRY(hipEventElapsedTime(&ms, y0, y1));
-                ctx->stats[LRSC_K_EXTEND].launches += 1;
-                ctx->stats[LRSC_K_EXTEND].total_ms += ms;       // overlaps the DP stage: the stage times no longer add up to wall time
-            }
-            HIP_TRY(hipMemcpy(ro.data(), d_out.p, (size_t)n * sizeof(ReadOut), hipMemcpyDeviceToHost));
-            if(std::getenv("LRSC_CORRECT_PROFILE"))
-                std::fprintf(stderr, "[lrsc] DP round %u: %zu parked + %zu yielded reads, %zu DP requests, %llu strings aligned\n", round,
-                             parked.size(), yielded.size(), reqs.size(), (unsigned long long)stage.n_strings);
-        }
-    }
-    a.n_reads = n;
-    if(a.walk_log) b->walk_log_done = true;
-    std::vector<uint32_t> pieces(std::max<uint64_t>(piece_total, 1));
-    if(piece_total) HIP_TRY(hipMemcpy(pieces.data(), d_pieces.p, (size_t)piece_total * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    if(std::getenv("LRSC_CORRECT_PROFILE")) {
-        double c[4] = {0, 0, 0, 0};
-        for(uint32_t r = 0; r < n; ++r) for(int j = 0; j < 4; ++j) c[j] += (double)ro[r].cyc[j];
-        const double tot = c[0] + c[1] + c[2] + c[3];
-        std::fprintf(stderr, "[lrsc] correct kernel lane-ticks: prepare %.1f%%, trees+root %.1f%%, extension loop %.1f%%, stitch+other %.1f%% (%.3g ticks)\n",
-                     100 * c[0] / tot, 100 * c[1] / tot, 100 * c[2] / tot, 100 * c[3] / tot, tot);
-        double s8[8] = {0, 0, 0, 0, 0, 0, 0, 0}, steps = 0;
-        for(uint32_t r = 0; r < n; ++r) { for(int j = 0; j < 8; ++j) s8[j] += (double)ro[r].cyc_step[j]; steps += (double)ro[r].steps; }
-        if(steps > 0 && c[2] > 0)
-            std::fprintf(stderr, "[lrsc] extension step (%.0f ticks avg over %.3g steps): extendLeaves %.1f%% (refine %.1f%%, attempToExtend %.1f%% of which getFMIndexExtensions %.1f%%), "
-                                 "PrunedBySeedSupport %.1f%%, materialise+commit %.1f%%, isTerminated %.1f%%\n",
-                         c[2] / steps, steps, 100 * s8[0] / c[2], 100 * s8[1] / c[2], 100 * s8[2] / c[2], 100 * s8[3] / c[2], 100 * s8[4] / c[2], 100 * s8[5] / c[2],
-                         100 * s8[6] / c[2]);
-    }
-    std::vector<uint64_t> dst_off(n + 1, 0);
-    uint64_t n_pieces = 0;
-    for(uint32_t r = 0; r < n; ++r) {
-        const ReadOut& o = ro[r];
-        int status = skipped[r];
-        if(o.error == LRSC_WALK_ERR_GEOMETRY) status = LRSC_READ_GEOMETRY;
-        else if(o.error == LRSC_WALK_ERR_CODE) status = LRSC_READ_INTERNAL;
-        else if(o.error == LRSC_WALK_ERR_DP) status = LRSC_READ_DP_LIMIT;
-        else if(o.error == LRSC_WALK_ERR_OUTPUT) status = LRSC_READ_OUTPUT_LIMIT;
-        else if(o.error != 0) status = LRSC_READ_FRONTIER_LIMIT;
-        if(status != LRSC_READ_OK) {
-            // this read alone could not be corrected: it comes back as "not merged" (-> discard.fa) with its status
-            lrsc_read_result& R = res[r];
-            std::memset(&R, 0, sizeof(R));
-            R.piece_first = n_pieces;
-            R.status = status;
-            dst_off[r + 1] = dst_off[r];
-            ro[r].out_len = 0;
-            continue;
-        }
-        lrsc_read_result& R = res[r];
-        R.merge = (int32_t)o.merge; R.n_pieces = o.n_pieces; R.piece_first = n_pieces;
-        R.total_reads_len = o.c[0]; R.corrected_len = o.c[1]; R.total_seed_num = o.c[2]; R.total_walk_num = o.c[3];
-        R.high_error_num = o.c[4]; R.exceed_depth_num = o.c[5]; R.exceed_leave_num = o.c[6]; R.fm_num = o.c[7];
-        R.dp_num = o.c[8]; R.seed_dis = o.c[9];
-        R.status = LRSC_READ_OK; R.pad = 0;
-        dst_off[r + 1] = dst_off[r] + o.out_len;
-        for(uint32_t j = 0; j < o.n_pieces; ++j) {
-            if(piece_off && n_pieces < piece_cap) piece_off[n_pieces] = dst_off[r] + pieces[work[r].piece_off + j];
-            ++n_pieces;
-        }
-    }
-    const uint64_t used = dst_off[n];
-    if(piece_off && n_pieces < piece_cap) piece_off[n_pieces] = used;
-    *n_pieces_out = n_pieces;
-    *out_used = used;
-    if(!out || !piece_off || used > out_cap || n_pieces + 1 > piece_cap) return fail(LRSC_ERR_CAPACITY, "output buffers too small");
-    if(used) {
-        HIP_TRY(d_dst_off.reserve(n + 1));
-        HIP_TRY(d_dst.reserve(used));
-        HIP_TRY(hipMemcpyAsync(d_dst_off.p, dst_off.data(), (size_t)(n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-        e = launch_correct_gather(a, d_dst_off.p, d_dst.p, ctx->stream);
-        if(e != hipSuccess) return hip_fail(e, "correct_gather");
-        HIP_TRY(hipMemcpyAsync(out, d_dst.p, used, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-    }
-    return LRSC_OK;
+    return batch_correct_wp(ctx, b, res, piece_off, piece_cap, out, out_cap, n_pieces_out, out_used);
 }
 
 // ---------------------------------------------------------------------------------------

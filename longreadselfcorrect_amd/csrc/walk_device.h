@@ -1,5 +1,5 @@
 // walk_device.h -- the device-side LongReadSelfCorrectByOverlap state machine (Leaf, Walk) shared by the
-// per-walk kernel (extend.hip) and the persistent per-read kernel (correct_dev.hip).
+// per-walk kernel (extend.hip) and the walk-parallel correction flow (wp.hip).
 // Reference: PacBio/LongReadCorrectByOverlap.cpp:17-878, FMIndexWalk/SAINode.cpp:166-189.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -204,6 +204,7 @@ struct Walk {
     uint32_t n_highfreq;              // children of the last attempToExtend whose k-mer frequency is above isInsufficientFreqs' threshold
     uint64_t steps;
     uint32_t leaf_steps;              // frontier leaves summed over the steps (profiling)
+    uint32_t max_front;               // widest frontier of the walk (profiling)
     uint64_t cyc_setup, cyc_loop;     // profiling: ticks spent building the trees/root and in the extension loop
     uint64_t* prof;                   // profiling: ReadOut::cyc_step of the read, or nullptr
     __device__ __forceinline__ uint64_t tick() const { return prof ? __builtin_readcyclecounter() : 0; }
@@ -909,6 +910,7 @@ struct Walk {
     {
         if(ended || error || !(n_cur != 0 && n_cur <= maxLeaves && currentLength <= maxLength)) return false;
         leaf_steps += n_cur;
+        if(n_cur > max_front) max_front = n_cur;
         if(profile) {                                    // two s_memtime round trips per step are not free: only when asked for
             const uint64_t t_step0 = __builtin_readcyclecounter();
             step_body();

@@ -30,7 +30,7 @@ struct alignas(16) WpSlot {
     uint64_t src_lo, src_hi;
     uint8_t k, next, rtou, flags;
     // DP identity (always for next = 0)
-    uint8_t dp_k, pad0, pad1, pad2;
+    uint8_t dp_k, max_front, pad1, pad2;     // max_front: widest frontier of the attempt (profiling)
     uint64_t dp_src_lo, dp_src_hi;
     // geometry of the FM attempt: m_query = k | gap | target (after the repeat-to-unique swap the target is k long)
     uint32_t lq, gap, trg_len, pathw;
@@ -215,6 +215,9 @@ struct WpSchedArgs {
     uint32_t quorum_pct;                 // idle lanes (in %) of a wavefront that wait for company before they pull their next walks
 };
 
+// bounds of every walk a read can be asked for (initCorrect's two loops, PacBioSelfCorrectionProcess.cpp:78-157): the source always
+// ends where seed it-1 ends and the target is seed it + next, next < nextTarget
+hipError_t launch_wp_bounds(const WpArgs& a, ReadPlan* plan, hipStream_t stream);
 hipError_t launch_wp_plan(const WpArgs& a, hipStream_t stream);
 hipError_t launch_wp_materialize(const WpArgs& a, hipStream_t stream);
 hipError_t launch_wp_prepare(const FmIndexDev& fm, const WpArgs& a, hipStream_t stream);

@@ -79,6 +79,29 @@ __device__ __forceinline__ void wp_sizes(const WpArgs& a, const WpSlot& s, uint3
 // ---------------------------------------------------------------------------------------
 // plan
 // ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wp_bounds_kernel(WpArgs a, ReadPlan* plan)
+{
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if(r >= a.n_reads) return;
+    const uint64_t rs = a.read_off[r];
+    const uint32_t n_seeds = a.seed_count[r];
+    const int32_t* seeds = a.seeds + seed_slab(rs, r, a.min_k) * kSeedInts;
+    uint32_t gap_max = 0, lq_max = 0;
+    for(uint32_t it = 1; it < n_seeds; ++it) {
+        const int s_end = seeds[(uint64_t)(it - 1) * kSeedInts] + seeds[(uint64_t)(it - 1) * kSeedInts + 1] - 1;
+        for(int next = 0; next < a.next_target && it + (uint32_t)next < n_seeds; ++next) {
+            const int32_t* T = seeds + (uint64_t)(it + (uint32_t)next) * kSeedInts;
+            const int gap = T[0] - s_end - 1;
+            if(gap < 0) continue;                               // the stitch pass reports it
+            if((uint32_t)gap > gap_max) gap_max = (uint32_t)gap;
+            const uint32_t lq = kMaxInitK + (uint32_t)gap + (uint32_t)T[1];
+            if(lq > lq_max) lq_max = lq;
+        }
+    }
+    plan[r].gap_max = gap_max;
+    plan[r].lq_max = lq_max;
+}
+
 __global__ __launch_bounds__(256) void wp_plan_kernel(WpArgs a)
 {
     const uint32_t r = a.r0 + blockIdx.x * 256 + threadIdx.x;
@@ -344,7 +367,7 @@ __global__ __launch_bounds__(64, 2) void wp_extend_kernel(FmIndexDev fm, WpArgs 
             W.minLength = (uint64_t)((0.8 * ((int32_t)s.gap - 20)) + (double)(2 * (uint64_t)s.k));
             W.cur = leaf_base; W.nxt = leaf_base + 32; W.leaf_small = leaf_base;
             W.error = 0;
-            steps0 = W.steps; W.leaf_steps = 0;
+            steps0 = W.steps; W.leaf_steps = 0; W.max_front = 1;
             const P riv[4] = {(P)H->root[0], (P)H->root[1], (P)H->root[2], (P)H->root[3]};
             W.begin_root(riv);
             in_walk = true;
@@ -366,7 +389,7 @@ __global__ __launch_bounds__(64, 2) void wp_extend_kernel(FmIndexDev fm, WpArgs 
         WpSlot& s = a.slots[si];
         uint32_t plen = 0, mi = 0;
         const int code = W.finish(&plen, s.path, &mi);
-        s.code = code; s.path_len = plen; s.match_i = mi; s.steps = (uint32_t)(W.steps - steps0); s.leaf_steps = W.leaf_steps;
+        s.code = code; s.path_len = plen; s.match_i = mi; s.steps = (uint32_t)(W.steps - steps0); s.leaf_steps = W.leaf_steps; s.max_front = (uint8_t)W.max_front;
         s.flags |= (uint8_t)kWpFmValid;
         if(code <= 0 && code > LRSC_WALK_ERR_CHILDREN && a.auto_dp && s.next == 0) {
             const uint32_t j = atomicAdd(a.n_dp_items, 1u);
@@ -423,7 +446,7 @@ __device__ __forceinline__ void wp_walk_consts(Walk<WIDE>& W, const FmIndexDev& 
     W.seedSize = a.seed_size; W.minOverlap = a.min_overlap; W.maxLeaves = a.max_leaves;
     W.PBcoverage = a.pb_coverage; W.PacBioErrorRate = a.pacbio_error_rate; W.errorRate = 0.25; W.localK = 100;
     W.freqsOfKmerSize = a.freqs_of_kmer_size;
-    W.n_rank = 0; W.n_blk = 0; W.steps = 0; W.leaf_steps = 0; W.error = 0; W.cyc_setup = 0; W.cyc_loop = 0; W.prof = nullptr; W.profile = false;
+    W.n_rank = 0; W.n_blk = 0; W.steps = 0; W.leaf_steps = 0; W.max_front = 1; W.error = 0; W.cyc_setup = 0; W.cyc_loop = 0; W.prof = nullptr; W.profile = false;
     W.n_nxt = 0; W.ended = false;
 }
 
@@ -476,7 +499,7 @@ __device__ __noinline__ void wp_walk_finish(Walk<WIDE>& W, const WpArgs& a, uint
     WpSlot& s = a.slots[si];
     uint32_t plen = 0, mi = 0;
     const int code = W.finish(&plen, s.path, &mi);
-    s.code = code; s.path_len = plen; s.match_i = mi; s.steps = (uint32_t)W.steps; s.leaf_steps = W.leaf_steps;
+    s.code = code; s.path_len = plen; s.match_i = mi; s.steps = (uint32_t)W.steps; s.leaf_steps = W.leaf_steps; s.max_front = (uint8_t)W.max_front;
     s.flags |= (uint8_t)kWpFmValid;
     if(code <= 0 && code > LRSC_WALK_ERR_CHILDREN && a.auto_dp && s.next == 0) {
         const uint32_t j = atomicAdd(a.n_dp_items, 1u);
@@ -874,6 +897,13 @@ __global__ __launch_bounds__(256) void wp_gather_kernel(WpArgs a, const uint64_t
 // ---------------------------------------------------------------------------------------
 // launch wrappers
 // ---------------------------------------------------------------------------------------
+hipError_t launch_wp_bounds(const WpArgs& a, ReadPlan* plan, hipStream_t stream)
+{
+    if(a.n_reads == 0) return hipSuccess;
+    hipLaunchKernelGGL(wp_bounds_kernel, dim3((a.n_reads + 255) / 256), dim3(256), 0, stream, a, plan);
+    return hipGetLastError();
+}
+
 hipError_t launch_wp_plan(const WpArgs& a, hipStream_t stream)
 {
     if(a.reqs) {

@@ -28,12 +28,12 @@ def _expected_walk_log(count, seeds, walks):
     return log
 
 
-@pytest.mark.parametrize("kernel", ["lane", "sm"])
+@pytest.mark.parametrize("kernel", ["one-kernel", "two-class"])
 @pytest.mark.parametrize("ds_name,nodp,split", [("repeat_ds", 0, 0), ("repeat_ds", 1, 1), ("small_ds", 0, 1)])
 def test_debug_collection_matches_oracle(api, oracle, request, ds_name, nodp, split, kernel, monkeypatch):
     """lrsc_batch_set_debug: dropped (hitchhiking) seeds, the repeat ratio per position and the failed-walk log."""
-    if kernel == "sm":
-        monkeypatch.setenv("LRSC_CORRECT_KERNEL", "sm")
+    if kernel == "two-class":
+        monkeypatch.setenv("LRSC_WP_SCHED", "1")
     ds = request.getfixturevalue(ds_name)
     n = 200
     off = ds.off[: n + 1].copy()
