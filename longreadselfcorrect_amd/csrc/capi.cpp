@@ -1469,7 +1469,7 @@ struct WpScratch {
     DevBuf<uint32_t> d_key, d_key_tmp, d_list, d_list_tmp, d_small;   // d_small: plan_stats[4], queue, n_dp_items, n_req
     DevBuf<WpDpItem> d_items;
     DevBuf<WpRequest> d_req;
-    DevBuf<uint8_t> d_prep, d_lane, d_lane_side, d_ctx[2];
+    DevBuf<uint8_t> d_prep, d_lane, d_lane_side, d_lane_side2, d_ctx[2];
     hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t ev_side[2] = {nullptr, nullptr}, ev_ready = nullptr;
     DevBuf<unsigned long long> d_prof;
@@ -1591,7 +1591,7 @@ static int batch_correct_wp(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result* res,
     }
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
-    uint32_t max_lanes = (uint32_t)cus * 4u * 4u * 64u;              // 4 wavefronts per SIMD (128 VGPRs)
+    uint32_t max_lanes = (uint32_t)cus * 4u * 2u * 64u;              // 2 wavefronts per SIMD (the extension kernels hold ~190 VGPRs)
     if(const char* ev = std::getenv("LRSC_WP_LANES")) max_lanes = (uint32_t)std::max(64, std::atoi(ev));
     uint64_t prep_budget = 24ull << 30, lane_budget = 32ull << 30;
     if(const char* ev = std::getenv("LRSC_WP_PREP_MB")) prep_budget = std::max<uint64_t>(1, (uint64_t)std::atoll(ev)) << 20;
@@ -1605,18 +1605,22 @@ static int batch_correct_wp(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result* res,
     }
     if(!ws.ev_ready) HIP_TRY(hipEventCreateWithFlags(&ws.ev_ready, hipEventDisableTiming));
 
-    uint32_t iso_div = 1;
-    if(const char* ev = std::getenv("LRSC_WP_ISO_DIV")) iso_div = (uint32_t)std::max(1, std::atoi(ev));
+    uint32_t mid_stride = 64;
+    if(const char* ev = std::getenv("LRSC_WP_MID_STRIDE")) { const int v = std::atoi(ev); if(v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) mid_stride = (uint32_t)v; }
     // One launch of the one-kernel form (wp_extend_kernel: every lane runs both kinds of step) over `count` list entries;
     // stride 64 = one walk per wavefront
+    bool reserve_side = false;
     auto extend_range = [&](WpArgs x, const uint32_t* list, const WpRequest* reqs, uint32_t count, uint32_t pathw, hipStream_t st, int which, uint32_t stride) -> hipError_t {
         if(count == 0) return hipSuccess;
         const WpLaneLayout LL = wp_lane_layout(lbytes, pathw);
-        // isolated walks (stride > 1) take at most a quarter of the wavefront slots when they run beside the bulk
-        uint64_t lanes = std::min<uint64_t>(stride == 1 ? (((uint64_t)count + 63) & ~63ull) : count, which ? max_lanes / stride / iso_div : max_lanes / stride);
+        // wavefront slots: the side launches (which != 0) and the bulk launch are persistent and share the device, so each gets a share
+        // of the resident wavefronts -- a launch that fills every slot first would keep the others out until it ends
+        const uint64_t slots = max_lanes / 64;                                        // resident wavefronts of these kernels
+        const uint64_t share = which == 1 ? slots / 8 : which == 2 ? slots / 4 : (reserve_side ? slots - slots / 8 - slots / 4 : slots);
+        uint64_t lanes = std::min<uint64_t>(stride == 1 ? (((uint64_t)count + 63) & ~63ull) : count, share * 64 / stride);
         lanes = std::max<uint64_t>(1, std::min<uint64_t>(lanes, (lane_budget / (which ? 4 : 1)) / LL.total));
         if(stride == 1) lanes = std::max<uint64_t>(64, lanes & ~63ull);
-        DevBuf<uint8_t>& buf = which ? ws.d_lane_side : ws.d_lane;
+        DevBuf<uint8_t>& buf = which == 2 ? ws.d_lane_side2 : which ? ws.d_lane_side : ws.d_lane;
         hipError_t e2 = buf.reserve(lanes * LL.total);
         if(e2 != hipSuccess) return e2;
         x.list = list; x.reqs = reqs; x.n_list = count;
@@ -1805,10 +1809,15 @@ static int batch_correct_wp(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result* res,
                 if(e2 != hipSuccess) return e2;
                 if(!use_sched) {
                     if(round != 0) return extend_range(a, a.list, a.reqs, n_ent, std::max(stats[2], 1u), ctx->stream, 0, n_ent <= 16384 ? 64u : n_ent <= 65536 ? 16u : 1u);
-                    // the walks across long gaps (the first n_mid of the launch order): one per wavefront, beside the bulk
-                    e2 = side_begin();
-                    if(e2 == hipSuccess) e2 = extend_range(a, ext_list, nullptr, n_mid, stats[2], ws.side[0], 1, 64);
-                    if(e2 == hipSuccess) e2 = extend_range(a, ext_list + n_mid, nullptr, n_ent - n_mid, std::min(stats[2], kWpPathwSmall), ctx->stream, 0, 1);
+                    // the walks across long gaps (the first n_mid of the launch order) run thinly spread over wavefronts: a lane-per-walk
+                    // wavefront advances at the pace of its slowest lane, and these are thousands of wide steps long.  They follow the bulk
+                    // (both launches are persistent and want every wavefront slot).
+                    e2 = extend_range(a, ext_list + n_mid, nullptr, n_ent - n_mid, std::min(stats[2], kWpPathwSmall), ctx->stream, 0, 1);
+                    if(e2 == hipSuccess) e2 = extend_range(a, ext_list, nullptr, n_mid, stats[2], ctx->stream, 0, mid_stride);
+                    return e2;
+                }
+                if(false) {
+                    reserve_side = false;
                     if(e2 == hipSuccess) e2 = side_join();
                     return e2;
                 }
