@@ -17,7 +17,8 @@ the timing barrier.
 One JSON line on stdout (rank 0):
   roofline      the graded Occ-rank kernel (kmer_grid_kernel) of the same run: algorithmic bytes (rank blocks +
                 k-mer table lines, 64 B each, counted on the device) / its HIP-event time on the ctx stream
-  roofline_extra  the same pricing for correct_reads_kernel (the FM-extension kernel, where the metric lives)
+  roofline_extra  the same pricing for the FM-extension kernels of the walk-parallel flow (wp_prepare / wp_begin / wp_extend: where
+                the metric lives)
   cpu_baseline  the CPU oracle (port of the reference algorithm) on all host cores, one thread per core over
                 disjoint reads of the first sub-batch, bounded to about --cpu-seconds
   parity_sample the oracle's corrected strings and integer counters for those sampled reads compared with what
@@ -54,10 +55,10 @@ STAGE_INFO = {
                   stages=["LongReadProbe k-mer feature grid (Occ-rank kernel)",
                           "getSeqAttribute + searchSeedsWithHybridKmers + estimateBestKmerSize + removeHitchhikingSeeds"]),
     "correct-nodp": dict(config=2, metric="corrected Mbases/s (whole node), --nodp flow",
-                         stages=["seed stage", "seed-to-seed FM-extension chain + stitching (correct_reads_kernel)",
+                         stages=["seed stage", "seed-to-seed FM-extension of every seed pair at once + per-read stitching (wp_* kernels)",
                                  "download of corrected strings + counters"]),
     "correct": dict(config=2, metric="corrected Mbases/s (whole node)",
-                    stages=["seed stage", "seed-to-seed FM-extension chain + stitching (correct_reads_kernel)",
+                    stages=["seed stage", "seed-to-seed FM-extension of every seed pair at once + per-read stitching (wp_* kernels)",
                             "DP/MSA fallback rounds (LF-walk retrieval, extendMatch, multiple alignment + consensus)",
                             "download of corrected strings + counters"]),
 }
@@ -168,7 +169,7 @@ def main():
     log(f"{len(groups)} sub-batch(es) of {reads_per_step} reads resident in HBM ({n_streams} concurrent part(s) each), "
         f"{int(off[-1]) / 1e6:.1f} Mbases in all")
 
-    totals = {"walks": 0, "fm": 0, "dp": 0, "corrected_reads": 0, "corrected_bases": 0}
+    totals = {"walks": 0, "fm": 0, "dp": 0, "corrected_reads": 0, "corrected_bases": 0, "not_ok": 0}
     kept = {}            # results of part 0 of sub-batch 0 from its latest pass (parity_sample compares them with the oracle)
 
     def correct_part(g, j, timed, acc):
@@ -176,7 +177,7 @@ def main():
         res, poff, out = b.correct()      # FM-extension chain (+ DP/MSA rounds) and stitching on the device; results on the host
         if timed:
             acc.append((sum(r.total_walk_num for r in res), sum(r.fm_num for r in res), sum(r.dp_num for r in res),
-                        sum(1 for r in res if r.merge), int(out.size)))
+                        sum(1 for r in res if r.merge), int(out.size), sum(1 for r in res if r.status != 0)))
         if g == 0 and j == 0:
             kept["res"], kept["poff"], kept["out"] = res, poff.copy(), out.copy()
 
@@ -195,7 +196,7 @@ def main():
                 for th in ths: th.start()
                 for th in ths: th.join()
             for a in acc:
-                for key, v in zip(("walks", "fm", "dp", "corrected_reads", "corrected_bases"), a):
+                for key, v in zip(("walks", "fm", "dp", "corrected_reads", "corrected_bases", "not_ok"), a):
                     totals[key] += v
         return group_bases[g]
 
@@ -250,11 +251,16 @@ def main():
         roof = roofline_of(K_GRID, "kmer_grid_kernel")
         # HBM-side traffic of the same kernel on the same launch shape comes from the committed rocprofv3 --pmc passes (counters
         # cannot be sampled from inside the process); null for any other workload
-        pmc = REPO / "profiles" / "r02_pmc" / "traffic.json"
+        pmc = REPO / "profiles" / "r03_pmc" / "traffic.json"
+        roof["peak_measured"] = measured_copy_peak(torch)
+        roof["frac_of_measured"] = roof["achieved"] / roof["peak_measured"] if roof["peak_measured"] else None
+        roof["peak_measured_how"] = "device-to-device copy of 4 GiB inside this run (read + write bytes / HIP-event time, best of 5)"
         if pmc.exists():
             pj = json.loads(pmc.read_text())
+            # the counters were collected for one build of the kernel: only quote them for that build
+            same_build = pj.get("kernel_source_sha256") == grid_kernel_source_hash()
             for shape in pj.get("shapes", [pj]):
-                if shape.get("reads_per_launch") == batches[0].n_reads and shape.get("index_reads") == n_reads and shape.get("read_len") == args.read_len:
+                if same_build and shape.get("reads_per_launch") == batches[0].n_reads and shape.get("index_reads") == n_reads and shape.get("read_len") == args.read_len:
                     roof["traffic"] = shape["traffic_bytes_per_launch"] / 1e9
                     roof["traffic_unit"] = "GB per launch (separate rocprofv3 --pmc passes, corrected as MI355X_MICROARCH.md prescribes)"
                     roof["traffic_source"] = shape["source"]
@@ -296,7 +302,8 @@ def main():
                 "concurrent_parts_per_step": n_streams,
                 **({} if args.stage == "seeds" else {
                     "walks": totals["walks"], "fm_walks": totals["fm"], "dp_walks": totals["dp"],
-                    "corrected_reads": totals["corrected_reads"], "corrected_bases_out": totals["corrected_bases"]}),
+                    "corrected_reads": totals["corrected_reads"], "corrected_bases_out": totals["corrected_bases"],
+                    "reads_status_not_ok": totals["not_ok"]}),
                 "index_hbm_gb": info.device_bytes / 1e9,
                 "index_build_s": build_s, "index_upload_and_tables_s": upload_s,
                 "reads_per_gpu": n_reads,
@@ -305,7 +312,7 @@ def main():
             "roofline": roof,
         }
         if args.stage != "seeds":
-            result["roofline_extra"] = [roofline_of(K_EXTEND, "correct_reads_kernel")]
+            result["roofline_extra"] = [roofline_of(K_EXTEND, "wp_prepare + wp_begin + wp_extend kernels (one timed group per round)")]
         if world == 1 and args.cpu_seconds > 0:
             cb, ps = cpu_baseline(units, n_reads, n_sym, params, bases, off, batches[0].n_reads, args, kept, batches[0])
             result["cpu_baseline"] = cb
@@ -325,6 +332,35 @@ def main():
     if rc:
         log("parity_sample: the GPU results differ from the CPU oracle's for the sampled reads")
         sys.exit(rc)
+
+
+def grid_kernel_source_hash() -> str:
+    """sha256 over the sources the Occ-rank kernel is compiled from (profiles/r03_pmc/traffic.json records the same digest)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in ("kernels.hip", "rank_device.h", "fm_device.h"):
+        h.update((REPO / "longreadselfcorrect_amd" / "csrc" / f).read_bytes())
+    return h.hexdigest()
+
+
+def measured_copy_peak(torch) -> float:
+    """Stream-copy rate of this GPU in GB/s (SURVEY.md section 8d asks for it beside the nominal peak)."""
+    try:
+        n = 1 << 30                                   # 4 GiB of int32
+        a = torch.empty(n, dtype=torch.int32, device="cuda")
+        b = torch.empty_like(a)
+        a.zero_()
+        best = 0.0
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); b.copy_(a); e1.record(); torch.cuda.synchronize()
+            best = max(best, 2 * 4 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+        del a, b
+        torch.cuda.empty_cache()
+        return best
+    except Exception:
+        return 0.0
 
 
 def host_cores() -> int:
@@ -401,7 +437,9 @@ def cpu_baseline(units, n_reads, n_sym, params, bases, off, batch0_reads, args, 
           "per_core": sample_bases / dt / 1e6 / threads,
           "sample": f"first {n} reads ({sample_bases / 1e6:.2f} Mbases) of sub-batch 0, "
                     f"{'seed stage (LongReadProbe::searchSeedsWithHybridKmers)' if stage == 'seeds' else 'whole per-read path (PacBioSelfCorrectionProcess::process, no_dp=%d)' % params.no_dp}, "
-                    f"oracle/ restatement over the reference's RLBWT layout (g++ -O3, no -march), {threads} threads x {n // threads} reads, {dt:.1f}s"}
+                    f"oracle/ restatement over the reference's RLBWT layout (g++ -O3, no -march), {threads} threads x {n // threads} reads, {dt:.1f}s; "
+                    f"the port runs at about 0.75x the reference binary's own per-core rate (0.030 vs 0.040 Mbases/s/core in BASELINE.md's "
+                    f"survey run: the reference itself cannot be built in this image)"}
     if stage == "seeds":
         # compare the seeds of the sampled reads with the GPU's
         count_g, seeds_g, _ = batch0.seeds(want_attribute=False)
