@@ -3,16 +3,11 @@
 //   dp_seed_kernel      lane per (request, direction): bi-interval of the source k-mer (query[0..k)) and of the
 //                       reverse-complemented target k-mer (revcomp(query[Lq-k..))): fwd = reverse(w) in the rBWT,
 //                       rvc = revcomp(w) in the BWT, each with findInterval's early exit (:681-682).
-//                       Round 1 built this kernel `optnone`.  Root cause, pinned on the GPU in round 2 with five source
-//                       variants of this loop (tools/dp_seed_variants.py, profiles/r02_dp_seed_variants.txt): with
-//                       `uint32_t c = q[..]; if(dir != 0) c = 3u - c;` -- a per-lane select between a zero-extended byte
-//                       and 3 minus it, so that the compiler only knows c in [-252, 255] -- ROCm 7.2 -O3 emits wrong
-//                       intervals for 27-29 of 60 requests (per-lane k or not, early break or not, with or without a
-//                       compiler barrier per step: all fail); the same loop with the character formed as
-//                       `(q[..] ^ (dir ? 3 : 0)) & 3` (range [0, 3] visible) matches the oracle 60 / 60 at -O3.  The shared
-//                       walk_step / update_interval code is unchanged and every other kernel feeds it characters straight
-//                       from byte loads; this kernel now uses the xor form and is built -O3 like the rest.
-//                       tests/test_gpu_fm.py::test_dp_consensus_matches_oracle (per-lane k in {13,15,17,19}) pins it.
+//                       Round 1 built this kernel `optnone`; the cause is pinned in rank_device.h (kSelectChainNote) and
+//                       profiles/r03_compiler_finding/: the select chain over a rank block's four counters is mis-lowered when
+//                       the compiler cannot bound the symbol code, which `c = q[..]; if(dir) c = 3u - c;` -- the form this loop
+//                       had -- provokes.  rank_device.h picks the base count by the code's bits now (LRSC_PICK4); this loop also forms its
+//                       character as `(q[..] ^ (dir ? 3 : 0)) & 3`.
 //   dp_retrieve_kernel  lane per retrieved string: starts at one row of such an interval (at most `coverage` rows
 //                       per interval, :685-687,:704-706) and LF-walks up to maxLength - k characters, stopping at '$'.
 //                       The string is written in the orientation retrieveMatches aligns (:697-700,:716-719):
@@ -45,7 +40,7 @@ __global__ __launch_bounds__(256) void dp_seed_kernel(FmIndexDev fm, DpPipeArgs 
         WalkState<P> st = walk_init<P>();
         for(uint32_t s = 0; s < k; ++s) {
             if(st.fwd_broken && st.rvc_broken) break;
-            // complement as xor + mask, NOT `c = q[..]; if(dir) c = 3u - c;`: see the note in the file header
+            // complement as xor + mask (range [0, 3] visible: see the note in the file header)
             const uint32_t c = ((uint32_t)q[dir == 0 ? s : lq - 1 - s] ^ (dir != 0 ? 3u : 0u)) & 3u;
             st = walk_step<WIDE>(sf, sr, c, k, st, mtab);
         }

@@ -6,6 +6,13 @@
 
 #include "kernels.h"
 
+// The block's base count for a symbol code, picked from the four counters by the code's two BITS (a binary tree of selects) and not by
+// an equality chain `code == 0 ? a : code == 1 ? b : code == 2 ? c : d`: the chain is mis-lowered by ROCm 7.2 -O3 when the compiler
+// cannot bound the code (kSelectChainNote below); bit tests are total functions of any 32-bit value, so no switch can be formed.
+#ifndef LRSC_PICK4
+#define LRSC_PICK4(code, a, b, c, d) (((code) & 2u) ? (((code) & 1u) ? (d) : (c)) : (((code) & 1u) ? (b) : (a)))
+#endif
+
 namespace lrsc {
 
 // ---------------------------------------------------------------------------------------
@@ -28,7 +35,7 @@ template <> struct Lay<false> {
     // symbols equal to `code` among the first `off` symbols of the block + the block's base count
     static __host__ __device__ __forceinline__ uint64_t count(const Regs& r, uint32_t code, const uint32_t* __restrict__ mrow)
     {
-        const uint32_t base = code == 0 ? (r.q[0].x & ~kFlag32) : code == 1 ? r.q[0].y : code == 2 ? r.q[0].z : r.q[0].w;
+        const uint32_t base = LRSC_PICK4(code, r.q[0].x & ~kFlag32, r.q[0].y, r.q[0].z, r.q[0].w);     // kSelectChainNote below
         const uint32_t L = (code & 1u) ? 0u : 0xFFFFFFFFu;
         const uint32_t H = (code & 2u) ? 0u : 0xFFFFFFFFu;
         const uint4 m0 = *reinterpret_cast<const uint4*>(mrow);
@@ -46,7 +53,7 @@ template <> struct Lay<false> {
     static __host__ __device__ __forceinline__ void count2(const Regs& r, uint32_t code, const uint32_t* __restrict__ mrow_a,
                                                   const uint32_t* __restrict__ mrow_b, uint64_t& ca, uint64_t& cb)
     {
-        const uint32_t base = code == 0 ? (r.q[0].x & ~kFlag32) : code == 1 ? r.q[0].y : code == 2 ? r.q[0].z : r.q[0].w;
+        const uint32_t base = LRSC_PICK4(code, r.q[0].x & ~kFlag32, r.q[0].y, r.q[0].z, r.q[0].w);
         const uint32_t L = (code & 1u) ? 0u : 0xFFFFFFFFu;
         const uint32_t H = (code & 2u) ? 0u : 0xFFFFFFFFu;
         const uint32_t m[6] = {(r.q[1].x ^ L) & (r.q[1].z ^ H), (r.q[1].y ^ L) & (r.q[1].w ^ H), (r.q[2].x ^ L) & (r.q[2].z ^ H),
@@ -90,8 +97,7 @@ template <> struct Lay<true> {
     static __host__ __device__ __forceinline__ bool flagged(const Regs& r) { return (r.q[0].y & 0x80000000u) != 0; }
     static __host__ __device__ __forceinline__ uint64_t count(const Regs& r, uint32_t code, const uint32_t* __restrict__ mrow)
     {
-        const uint64_t base = code == 0 ? (u64(r.q[0].x, r.q[0].y) & ~kFlag64) : code == 1 ? u64(r.q[0].z, r.q[0].w)
-                            : code == 2 ? u64(r.q[1].x, r.q[1].y) : u64(r.q[1].z, r.q[1].w);
+        const uint64_t base = LRSC_PICK4(code, u64(r.q[0].x, r.q[0].y) & ~kFlag64, u64(r.q[0].z, r.q[0].w), u64(r.q[1].x, r.q[1].y), u64(r.q[1].z, r.q[1].w));
         const uint32_t L = (code & 1u) ? 0u : 0xFFFFFFFFu;
         const uint32_t H = (code & 2u) ? 0u : 0xFFFFFFFFu;
         const uint4 m0 = *reinterpret_cast<const uint4*>(mrow);
@@ -105,8 +111,7 @@ template <> struct Lay<true> {
     static __host__ __device__ __forceinline__ void count2(const Regs& r, uint32_t code, const uint32_t* __restrict__ mrow_a,
                                                   const uint32_t* __restrict__ mrow_b, uint64_t& ca, uint64_t& cb)
     {
-        const uint64_t base = code == 0 ? (u64(r.q[0].x, r.q[0].y) & ~kFlag64) : code == 1 ? u64(r.q[0].z, r.q[0].w)
-                            : code == 2 ? u64(r.q[1].x, r.q[1].y) : u64(r.q[1].z, r.q[1].w);
+        const uint64_t base = LRSC_PICK4(code, u64(r.q[0].x, r.q[0].y) & ~kFlag64, u64(r.q[0].z, r.q[0].w), u64(r.q[1].x, r.q[1].y), u64(r.q[1].z, r.q[1].w));
         const uint32_t L = (code & 1u) ? 0u : 0xFFFFFFFFu;
         const uint32_t H = (code & 2u) ? 0u : 0xFFFFFFFFu;
         const uint32_t m[4] = {(r.q[2].x ^ L) & (r.q[3].x ^ H), (r.q[2].y ^ L) & (r.q[3].y ^ H), (r.q[2].z ^ L) & (r.q[3].z ^ H),
@@ -269,19 +274,20 @@ __host__ __device__ __forceinline__ IvT<typename Lay<WIDE>::pos_t> update_interv
 }
 
 // ---------------------------------------------------------------------------------------
-// updateInterval with the block's base count fetched by its own dword load (address = block + 4 * code) instead of a
-// select over the four loaded counters.  Why: with the select chain, ROCm 7.2 -O3 lowers `code == 0 ? x : code == 1 ? y :
-// code == 2 ? z : w` over just-loaded registers into exec-masked branches in some kernels (dp_seed_kernel in round 1,
-// the state-machine R-phase in round 2), and those kernels then return intervals that are off by a constant for
-// code 3 ('T') -- traced on the GPU against the CPU run of the same source (tools/sm_trace.py).  The extra load hits
-// the line that is being fetched anyway.  Counts never reach the flag bit (N < 2^31 for Block32, < 2^63 for Block64),
-// so the flag is masked off for every code.
+// kSelectChainNote -- the compiler finding of rounds 1-2, closed in round 3 (profiles/r03_compiler_finding/README.md,
+// tools/repro_complement/repro.hip).  Lay::count / count2 used to pick the block's base count with an equality chain over the
+// symbol code.  When the compiler cannot bound the code to [0, 3] (a caller formed it as `3u - byte`), ROCm 7.2 -O3 lowers such a
+// chain as a switch and leaves the code-3 arm without its `v_mov base, cnt[3]`: intervals that consumed a 'T' come back off by
+// a constant.  The chain is gone: LRSC_PICK4 selects by the code's two bits.  The variants below fetch the base count by its own
+// dword load at block + 4 * code instead (no select at all; the load hits the line that is being fetched anyway); they date from
+// the time the cause was not pinned and stay where they are measured no slower.  Counts never reach the flag bit (N < 2^31 for
+// Block32, < 2^63 for Block64), so the flag is masked off for every code.
 // ---------------------------------------------------------------------------------------
 template <bool WIDE>
 __host__ __device__ __forceinline__ uint64_t block_base(const void* blocks, uint64_t b, uint32_t code)
 {
-    if(WIDE) return reinterpret_cast<const uint64_t*>(reinterpret_cast<const Block64*>(blocks) + b)[code] & ~kFlag64;
-    return reinterpret_cast<const uint32_t*>(reinterpret_cast<const Block32*>(blocks) + b)[code] & ~kFlag32;
+    if(WIDE) return reinterpret_cast<const uint64_t*>(reinterpret_cast<const Block64*>(blocks) + b)[code & 3u] & ~kFlag64;
+    return reinterpret_cast<const uint32_t*>(reinterpret_cast<const Block32*>(blocks) + b)[code & 3u] & ~kFlag32;
 }
 // symbols equal to `code` among the first `off` symbols of the block (mask row given), without the base count
 template <bool WIDE>
