@@ -1198,7 +1198,7 @@ struct DpStage {
     DevBuf<DpJob> d_jobs;
     DevBuf<DpAlignOut> d_align;
     DevBuf<uint32_t> d_list;
-    DevBuf<uint8_t> d_msa_ws;
+    DevBuf<uint8_t> d_msa_ws, d_seq_ws;
     uint64_t cons_total = 0, n_strings = 0;
     // the MSA size buckets of a round run concurrently on side streams (each bucket's launch ends with a tail of a few long
     // pile-ups; serialised, those tails cost more than the work)
@@ -1230,9 +1230,9 @@ struct DpStage {
             r.w_cols = dp_msa_columns(r.lq);
             r.cons_off = cons_total;
             cons_total += r.cons_cap;
-            // beyond the alignment kernel's LDS staging (query + one retrieved string: about 30 kb of query): this request alone
-            // fails (its read gets LRSC_READ_DP_LIMIT), the rest of the round goes on
-            if(((r.lq + 2 + 3) & ~3u) + 264 + r.str_cap + 16 > 64 * 1024) too_long[(size_t)(&r - reqs.data())] = 1;
+            // beyond the alignment kernel's LDS staging (query + one retrieved string: about 30 kb of query): its alignments go through the
+            // global-workspace variant of the kernel in a second launch
+            if(dp_align_stage_bytes(r.lq, r.str_cap) > kDpAlignLdsCap) too_long[(size_t)(&r - reqs.data())] = 1;
         }
         HIP_TRY(d_reqs.reserve(n));
         HIP_TRY(d_msa.reserve(n));
@@ -1249,17 +1249,19 @@ struct DpStage {
         const uint32_t n_waves = dp_wave_count(ctx);
         uint32_t begin = 0;
         while(begin < n) {
-            uint32_t end = begin, max1 = 1, max2 = 1, lds = 0;
+            uint32_t end = begin, max1 = 1, max2 = 1, lds = 0, max1_long = 0, max2_long = 0;
+            uint64_t jobs_long = 0;
             uint64_t jobs = 0, sbytes = 0, obytes = 0;
             while(end < n) {
                 DpRequest& r = reqs[end];
-                r.n_str = too_long[end] ? 0u : r.cnt[0] + r.cnt[1] + r.cnt[2] + r.cnt[3];
+                r.n_str = r.cnt[0] + r.cnt[1] + r.cnt[2] + r.cnt[3];
                 any_too_long = any_too_long || too_long[end];
                 const uint64_t sb = (uint64_t)r.n_str * r.str_cap, ob = (uint64_t)r.n_str * r.ops_cap;
                 if(end > begin && sbytes + obytes + sb + ob + (jobs + r.n_str) * (sizeof(DpJob) + sizeof(DpAlignOut)) > budget) break;
                 r.job_first = jobs; r.str_off = sbytes; r.ops_off = obytes;
                 jobs += r.n_str; sbytes += sb; obytes += ob;
                 if(!too_long[end]) { max1 = std::max(max1, r.lq); max2 = std::max(max2, r.str_cap); }
+                else { max1_long = std::max(max1_long, r.lq); max2_long = std::max(max2_long, r.str_cap); jobs_long += r.n_str; }
                 lds = std::max(lds, dp_msa_lds_bytes(r.w_cols, r.str_cap, r.ops_cap, r.n_str));
                 ++end;
             }
@@ -1288,8 +1290,22 @@ struct DpStage {
                 const uint32_t nw = (uint32_t)nw64;
                 HIP_TRY(d_trace.reserve(al.trace_stride * nw));
                 al.trace = d_trace.p;
+                al.lds_cap = kDpAlignLdsCap;
                 st = timed_launch(ctx, LRSC_K_DP, [&]() { return launch_dp_align(al, nw, ctx->stream); });
                 if(st != LRSC_OK) return st;
+                if(jobs_long) {
+                    // the alignments of requests beyond the LDS stage: same kernel, sequences staged in a global slice per wavefront
+                    DpAlignArgs gl = al;
+                    gl.max_s1 = max1_long; gl.max_s2 = max2_long; gl.only_long = 1;
+                    gl.trace_stride = (uint64_t)(max1_long + 17) * kDpTraceStride;
+                    gl.seq_ws_stride = (dp_align_stage_bytes(max1_long, max2_long) + 255) & ~255ull;
+                    const uint32_t nwl = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(jobs_long, 1024), (4ull << 30) / gl.trace_stride));
+                    HIP_TRY(d_trace.reserve(gl.trace_stride * nwl));
+                    HIP_TRY(d_seq_ws.reserve(gl.seq_ws_stride * nwl));
+                    gl.trace = d_trace.p; gl.seq_ws = d_seq_ws.p;
+                    st = timed_launch(ctx, LRSC_K_DP, [&]() { return launch_dp_align(gl, nwl, ctx->stream); });
+                    if(st != LRSC_OK) return st;
+                }
             }
             if(std::getenv("LRSC_CORRECT_PROFILE") && begin == 0 && jobs) {
                 std::vector<DpAlignOut> ao(jobs);
@@ -1404,13 +1420,7 @@ struct DpStage {
             n_strings += jobs;
             begin = end;
         }
-        if(any_too_long) {
-            DpMsaOut bad{};
-            bad.error = 3;
-            for(uint32_t i = 0; i < n; ++i)
-                if(too_long[i]) HIP_TRY(hipMemcpyAsync(d_msa.p + i, &bad, sizeof(bad), hipMemcpyHostToDevice, ctx->stream));
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
-        }
+        (void)any_too_long;
         return LRSC_OK;
     }
 };
@@ -2034,9 +2044,11 @@ extern "C" int lrsc_dp_align(lrsc_ctx* ctx, const char* seq, uint64_t seq_len, c
         ops_total += (uint64_t)j.s1_len + j.s2_len + 1;
         max1 = std::max(max1, j.s1_len); max2 = std::max(max2, j.s2_len);
     }
-    if(((max1 + 2 + 3) & ~3u) + 264 + ((max2 + 3) & ~3u) + 16 > 64 * 1024) return fail(LRSC_ERR_UNSUPPORTED, "dp job: s1 + s2 must fit the 64 KB LDS stage");
-    const uint32_t n_waves = std::min<uint32_t>(dp_wave_count(ctx), n);
-    DevBuf<uint8_t> d_codes, d_ops, d_trace;
+    // sequences beyond the 64 KB LDS stage: the same kernel with its staging in a global slice per wavefront (fewer wavefronts)
+    const bool global_stage = dp_align_stage_bytes(max1, max2) > kDpAlignLdsCap;
+    const uint64_t stage_stride = (dp_align_stage_bytes(max1, max2) + 255) & ~255ull;
+    const uint32_t n_waves = std::min<uint32_t>(global_stage ? 1024u : dp_wave_count(ctx), n);
+    DevBuf<uint8_t> d_codes, d_ops, d_trace, d_stage;
     DevBuf<DpJob> d_jobs;
     DevBuf<DpAlignOut> d_out;
     DpAlignArgs a{};
@@ -2051,6 +2063,11 @@ extern "C" int lrsc_dp_align(lrsc_ctx* ctx, const char* seq, uint64_t seq_len, c
     a.codes = d_codes.p; a.strings = d_codes.p; a.jobs = d_jobs.p; a.n_jobs = n; a.band_width = (uint32_t)band_width;
     a.match_score = match_score; a.gap_penalty = gap_penalty; a.mismatch_penalty = mismatch_penalty;
     a.ops = d_ops.p; a.out = d_out.p; a.trace = d_trace.p; a.max_s1 = max1; a.max_s2 = max2;
+    a.lds_cap = kDpAlignLdsCap;
+    if(global_stage) {
+        HIP_TRY(d_stage.reserve(stage_stride * n_waves));
+        a.seq_ws = d_stage.p; a.seq_ws_stride = stage_stride; a.only_long = 0;
+    }
     st = timed_launch(ctx, LRSC_K_DP, [&]() { return launch_dp_align(a, n_waves, ctx->stream); });
     if(st != LRSC_OK) return st;
     std::vector<DpAlignOut> out(n);

@@ -44,9 +44,12 @@ __device__ __forceinline__ int lane_below(int old, int x) { return dpp<0x138>(ol
 __device__ __forceinline__ int lane_above(int old, int x) { return dpp<0x130>(old, x); }     // value of lane + 1
 } // namespace
 
+template <bool GLOBAL>
 __global__ __launch_bounds__(64) void dp_align_kernel(DpAlignArgs a)
 {
-    extern __shared__ uint8_t smem[];
+    extern __shared__ uint8_t lds[];
+    // the two sequences are staged in LDS, or -- for the few alignments beyond it -- in this wavefront's slice of a global workspace
+    uint8_t* smem = GLOBAL ? a.seq_ws + (uint64_t)blockIdx.x * a.seq_ws_stride : lds;
     uint8_t* S1 = smem;                                        // s1 codes, S1[L1] = 4 (the string's NUL)
     // s2 codes at S2[0 .. L2), sentinel 4 in the kS2Pad bytes before and the 16 after: a lane's five characters
     // s2[j-1 .. j+3] are then two aligned dword reads for any band position
@@ -71,10 +74,20 @@ __global__ __launch_bounds__(64) void dp_align_kernel(DpAlignArgs a)
             continue;
         }
         const int L1 = (int)J.s1_len, L2 = (int)J.s2_len;
+        {
+            // an alignment beyond the LDS stage belongs to the global-workspace launch (and only those do)
+            // (classified by the owning request's capacities, as the host sized the two launches: a long query with a short retrieved
+            //  string is still long)
+            const bool is_long = a.reqs ? dp_align_stage_bytes(a.reqs[J.req].lq, a.reqs[J.req].str_cap) > a.lds_cap
+                                        : dp_align_stage_bytes(J.s1_len, J.s2_len) > a.lds_cap;
+            if(GLOBAL ? (a.only_long && !is_long) : is_long) continue;
+        }
         __syncthreads();
+        if(GLOBAL) __threadfence_block();
         for(int i = (int)lane; i <= L1; i += 64) S1[i] = i < L1 ? a.codes[J.s1_off + i] : (uint8_t)4;
         for(int j = (int)lane; j < L2 + 16; j += 64) S2[j] = j < L2 ? a.strings[J.s2_off + j] : (uint8_t)4;
         __syncthreads();
+        if(GLOBAL) __threadfence_block();
         if(J.mode != 0 && L2 >= L1) {                              // identical sequence from the forward / backward extension
             const int shift = J.mode == 1 ? 0 : L2 - L1;
             bool diff = false;
@@ -238,10 +251,15 @@ hipError_t launch_dp_align(const DpAlignArgs& a, uint32_t n_waves, hipStream_t s
 {
     if(a.n_jobs == 0) return hipSuccess;
     if(a.band_width < 2 || (a.band_width / 2) * 2 + 1 > kDpMaxBand) return hipErrorInvalidValue;
-    const size_t lds = ((a.max_s1 + 2 + 3) & ~3u) + kS2Pad + ((a.max_s2 + 3) & ~3u) + 16;
-    if(lds > 64 * 1024) return hipErrorInvalidValue;
+    const size_t lds = dp_align_stage_bytes(a.max_s1, a.max_s2);
     if(n_waves > a.n_jobs) n_waves = a.n_jobs;
-    hipLaunchKernelGGL(dp_align_kernel, dim3(n_waves), dim3(64), lds, stream, a);
+    if(a.seq_ws) {
+        if(a.seq_ws_stride < lds) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(dp_align_kernel<true>, dim3(n_waves), dim3(64), 0, stream, a);
+    } else {
+        if(lds > kDpAlignLdsCap) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(dp_align_kernel<false>, dim3(n_waves), dim3(64), lds, stream, a);
+    }
     return hipGetLastError();
 }
 

@@ -85,12 +85,21 @@ struct DpAlignArgs {
     DpAlignOut* out;
     uint8_t* trace;               // n_waves x trace_stride
     uint64_t trace_stride;        // (max s1_len + 1) * kDpTraceStride
-    uint32_t max_s1, max_s2;      // LDS staging sizes
+    uint32_t max_s1, max_s2;      // staging sizes
     const DpRequest* reqs;        // optional
+    // staging of the two sequences: LDS (seq_ws == nullptr; jobs that do not fit lds_cap are left to a second launch) or, for the few
+    // alignments beyond it (a raw segment of tens of kb between two seeds), a per-wavefront slice of this global workspace
+    uint8_t* seq_ws;
+    uint64_t seq_ws_stride;
+    uint32_t lds_cap;
+    uint32_t only_long;           // global variant: do only the jobs the LDS launch skipped
 };
 
 // n_waves = gridDim.x; every wave loops over jobs wave, wave + n_waves, ...
 hipError_t launch_dp_align(const DpAlignArgs& a, uint32_t n_waves, hipStream_t stream);
+// bytes of sequence staging one alignment needs (LDS or global slice)
+constexpr uint32_t dp_align_stage_bytes(uint32_t s1_len, uint32_t s2_len) { return ((s1_len + 2 + 3) & ~3u) + 264u + ((s2_len + 3) & ~3u) + 16u; }
+constexpr uint32_t kDpAlignLdsCap = 64u * 1024u;
 // lane per (request, direction): the two seed k-mers' bi-intervals -> row_lo / cnt
 hipError_t launch_dp_seeds(const FmIndexDev& fm, const DpPipeArgs& a, hipStream_t stream);
 // lane per retrieved string: LF-walk (retrieveStr), writes the string in its final orientation and its DpJob

@@ -121,6 +121,7 @@ class Oracle:
 
     def dp_consensus(self, bwt, rbwt, query: str, k: int, min_overlap: int, min_identity: float, coverage: int, min_call_coverage: int):
         """buildMultipleAlignment + calculateBaseConsensus -> (rows, consensus, retrieved strings)."""
+        self._decl_late()
         out = C.create_string_buffer(4 * len(query) + 1024)
         n3 = np.zeros(3, dtype=np.int32)
         rows = self.lib.orc_dp_consensus(bwt.h, rbwt.h, query.encode(), k, min_overlap, min_identity, coverage, min_call_coverage, out,

@@ -619,16 +619,17 @@ def test_whole_path_ragged_and_foreign_reads(api, gpu_index, oracle, small_ds, n
 
 
 def test_per_read_capacity_limits_do_not_fail_the_batch(api, gpu_index, oracle, small_ds):
-    """A read whose walk query would be >= 65535 bases, and one whose DP-fallback query is beyond the alignment kernel's staging
-    (about 30 kb), come back uncorrected with a per-read status; every other read of the batch is corrected exactly as the oracle
-    does (the reference itself has no such bounds: SURVEY.md section 8b, include/lrsc.h lrsc_read_status)."""
+    """A read whose walk query would be >= 65535 bases comes back uncorrected with a per-read status; every other read of the batch
+    is corrected exactly as the oracle does -- including one whose DP-fallback query (a 36 kb gap between two seeds) is beyond the
+    alignment kernel's LDS staging: its alignments run through the global-workspace variant of the kernel (the reference has no
+    bound there: Thirdparty/overlapper.cpp:421-701, PacBio/LongReadOverlap.cpp:17-55)."""
     from oracle.oracle_py import pack_reads
 
     rng = np.random.default_rng(99)
     reads = list(small_ds.reads[:12])
     junk = lambda n: "".join("ACGT"[i] for i in rng.integers(0, 4, n))
     far = reads[0][:1000] + junk(70000) + reads[1][-1000:]          # the only seeds are 70 kb apart: walk query too long
-    dpl = reads[2][:1000] + junk(36000) + reads[3][-1000:]          # 36 kb gap: FM-extension fails, the DP query is beyond the kernel's staging
+    dpl = reads[2][:1000] + junk(36000) + reads[3][-1000:]          # 36 kb gap: FM-extension fails, the DP query is beyond the LDS staging
     batch = reads[:6] + [far] + reads[6:9] + [dpl] + reads[9:]
     bases, off = pack_reads(batch)
     p = api.params_default(5, 90)
@@ -636,8 +637,7 @@ def test_per_read_capacity_limits_do_not_fail_the_batch(api, gpu_index, oracle, 
     results, pieces = ctx.correct_reads(bases, off)
     ctx.close()
     assert results[6].status == 1 and results[6].merge == 0 and pieces[6] == []
-    assert results[10].status == 5 and results[10].merge == 0 and pieces[10] == []
-    ok = [i for i in range(len(batch)) if i not in (6, 10)]
+    ok = [i for i in range(len(batch)) if i != 6]
     assert all(results[i].status == 0 for i in ok)
     ob, orb = oracle.bwt_load(small_ds.prefix + ".bwt"), oracle.bwt_load(small_ds.prefix + ".rbwt")
     b2, o2 = pack_reads([batch[i] for i in ok])
