@@ -1477,7 +1477,8 @@ struct WpScratch {
     DevBuf<WpSlot> d_slots;
     DevBuf<uint64_t> d_sz;                 // three arrays of (entries + 1)
     DevBuf<uint32_t> d_key, d_key_tmp, d_list, d_list_tmp, d_small;   // d_small: plan_stats[4], queue, n_dp_items, n_req
-    DevBuf<WpDpItem> d_items;
+    DevBuf<WpDpItem> d_items, d_items2;
+    hipEvent_t ev_side_t0 = nullptr, ev_side_t1 = nullptr;
     DevBuf<WpRequest> d_req;
     DevBuf<uint8_t> d_prep, d_lane, d_lane_side, d_lane_side2, d_ctx[2];
     hipStream_t side[2] = {nullptr, nullptr};
@@ -1496,6 +1497,8 @@ struct WpScratch {
             if(ev_side[i]) (void)hipEventDestroy(ev_side[i]);
         }
         if(ev_ready) (void)hipEventDestroy(ev_ready);
+        if(ev_side_t0) (void)hipEventDestroy(ev_side_t0);
+        if(ev_side_t1) (void)hipEventDestroy(ev_side_t1);
     }
 };
 
@@ -1626,7 +1629,7 @@ static int batch_correct_wp(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result* res,
         // wavefront slots: the side launches (which != 0) and the bulk launch are persistent and share the device, so each gets a share
         // of the resident wavefronts -- a launch that fills every slot first would keep the others out until it ends
         const uint64_t slots = max_lanes / 64;                                        // resident wavefronts of these kernels
-        const uint64_t share = which == 1 ? slots / 8 : which == 2 ? slots / 4 : (reserve_side ? slots - slots / 8 - slots / 4 : slots);
+        const uint64_t share = which == 1 ? slots / 2 : which == 2 ? slots / 4 : (reserve_side ? slots - slots / 8 - slots / 4 : slots);
         uint64_t lanes = std::min<uint64_t>(stride == 1 ? (((uint64_t)count + 63) & ~63ull) : count, share * 64 / stride);
         lanes = std::max<uint64_t>(1, std::min<uint64_t>(lanes, (lane_budget / (which ? 4 : 1)) / LL.total));
         if(stride == 1) lanes = std::max<uint64_t>(64, lanes & ~63ull);
@@ -1802,7 +1805,8 @@ static int batch_correct_wp(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result* res,
 
             // launch order of round 0: long walks first (the few walks across long gaps need bigger path slots: own launches)
             const uint32_t* ext_list = a.list;
-            uint32_t n_big = 0, n_mid = 0;
+            uint32_t n_big = 0, n_mid = 0, n_long_cap = 0;
+            bool long_launch = false, long_pending = false;
             if(round == 0) {
                 // list_tmp = slot_base + i
                 hlist.resize(n_ent);
@@ -1823,12 +1827,11 @@ static int batch_correct_wp(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result* res,
                     // wavefront advances at the pace of its slowest lane, and these are thousands of wide steps long.  They follow the bulk
                     // (both launches are persistent and want every wavefront slot).
                     e2 = extend_range(a, ext_list + n_mid, nullptr, n_ent - n_mid, std::min(stats[2], kWpPathwSmall), ctx->stream, 0, 1);
-                    if(e2 == hipSuccess) e2 = extend_range(a, ext_list, nullptr, n_mid, stats[2], ctx->stream, 0, mid_stride);
-                    return e2;
-                }
-                if(false) {
-                    reserve_side = false;
-                    if(e2 == hipSuccess) e2 = side_join();
+                    if(e2 != hipSuccess || n_mid == 0) return e2;
+                    if(p.no_dp) return extend_range(a, ext_list, nullptr, n_mid, stats[2], ctx->stream, 0, mid_stride);
+                    // with the DP fallback on they start on a side stream once the bulk is through and share the device with the DP
+                    // stage of the bulk's failed walks (own DP item list; half of the wavefront slots)
+                    long_launch = true;
                     return e2;
                 }
                 Pool pools[2];
@@ -1850,17 +1853,34 @@ static int batch_correct_wp(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result* res,
                 return e2;
             });
             if(st != LRSC_OK) return st;
+            if(long_launch) {
+                long_launch = false;
+                n_long_cap = n_mid;
+                HIP_TRY(ws.d_items2.reserve(n_mid));
+                WpArgs xl = a;
+                xl.dp_items = ws.d_items2.p; xl.n_dp_items = ws.d_small.p + 12; xl.dp_items_cap = n_mid;
+                xl.ctr = nullptr;                                       // the main stream's launches own the statistics counters
+                HIP_TRY(side_begin());
+                if(!ws.ev_side_t0) HIP_TRY(hipEventCreate(&ws.ev_side_t0));
+                HIP_TRY(hipEventRecord(ws.ev_side_t0, ws.side[0]));
+                e = extend_range(xl, ext_list, nullptr, n_mid, stats[2], ws.side[0], 1, mid_stride);
+                if(e != hipSuccess) return hip_fail(e, "wp_extend (long walks)");
+                long_pending = true;
+            }
 
             // ---- the DP stage for every failed walk of this round (and the explicit requests) ---------------------------------
             uint32_t n_items = 0;
-            HIP_TRY(hipMemcpy(&n_items, a.n_dp_items, sizeof(uint32_t), hipMemcpyDeviceToHost));
-            if(n_items > n_ent) return fail(LRSC_ERR_LIMIT, "walk-parallel flow: DP item list overflow");
-            if(n_items != 0) {
-                items.resize(n_items);
-                HIP_TRY(hipMemcpy(items.data(), ws.d_items.p, (size_t)n_items * sizeof(WpDpItem), hipMemcpyDeviceToHost));
+            auto run_dp = [&](DevBuf<WpDpItem>& d_list, const uint32_t* d_count, uint32_t cap) -> int {
+                uint32_t cnt = 0;
+                HIP_TRY(hipMemcpy(&cnt, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost));
+                if(cnt > cap) return fail(LRSC_ERR_LIMIT, "walk-parallel flow: DP item list overflow");
+                n_items += cnt;
+                if(cnt == 0) return LRSC_OK;
+                items.resize(cnt);
+                HIP_TRY(hipMemcpy(items.data(), d_list.p, (size_t)cnt * sizeof(WpDpItem), hipMemcpyDeviceToHost));
                 std::sort(items.begin(), items.end(), [](const WpDpItem& x, const WpDpItem& y) { return x.slot < y.slot; });
                 reqs.clear();
-                reqs.reserve(n_items);
+                reqs.reserve(cnt);
                 for(const WpDpItem& it : items) {
                     DpRequest q;
                     std::memset(&q, 0, sizeof(q));
@@ -1883,10 +1903,29 @@ static int batch_correct_wp(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result* res,
                 uint8_t* cons_keep = nullptr;
                 HIP_TRY(ws.persist.alloc(stage.cons_total + 64, &cons_keep));
                 HIP_TRY(hipMemcpyAsync(cons_keep, stage.d_cons.p, stage.cons_total, hipMemcpyDeviceToDevice, ctx->stream));
-                HIP_TRY(hipMemcpyAsync(ws.d_items.p, items.data(), (size_t)n_items * sizeof(WpDpItem), hipMemcpyHostToDevice, ctx->stream));
-                a.dp_reqs = stage.d_reqs.p; a.dp_msa = stage.d_msa.p; a.dp_cons = cons_keep; a.n_dp = n_items;
-                e = launch_wp_dp_collect(a, ws.d_items.p, ctx->stream);
-                if(e != hipSuccess) return hip_fail(e, "wp_dp_collect");
+                HIP_TRY(hipMemcpyAsync(d_list.p, items.data(), (size_t)cnt * sizeof(WpDpItem), hipMemcpyHostToDevice, ctx->stream));
+                WpArgs c2 = a;
+                c2.dp_reqs = stage.d_reqs.p; c2.dp_msa = stage.d_msa.p; c2.dp_cons = cons_keep; c2.n_dp = cnt;
+                hipError_t ec = launch_wp_dp_collect(c2, d_list.p, ctx->stream);
+                if(ec != hipSuccess) return hip_fail(ec, "wp_dp_collect");
+                HIP_TRY(hipStreamSynchronize(ctx->stream));                                  // `items` / the stage's buffers are reused by the next call
+                return LRSC_OK;
+            };
+            {
+                const int sd = run_dp(ws.d_items, a.n_dp_items, n_ent);
+                if(sd != LRSC_OK) return sd;
+            }
+            if(long_pending) {
+                // the long-gap walks ran on the side stream while the DP stage answered the bulk's failures: theirs now
+                if(!ws.ev_side_t1) HIP_TRY(hipEventCreate(&ws.ev_side_t1));
+                HIP_TRY(hipEventRecord(ws.ev_side_t1, ws.side[0]));
+                HIP_TRY(hipEventSynchronize(ws.ev_side_t1));
+                float ms = 0.f;
+                HIP_TRY(hipEventElapsedTime(&ms, ws.ev_side_t0, ws.ev_side_t1));
+                ctx->stats[LRSC_K_EXTEND].total_ms += ms;             // overlaps the DP stage: the stage times then add up to more than the wall time
+                long_pending = false;
+                const int sd = run_dp(ws.d_items2, ws.d_small.p + 12, n_long_cap);
+                if(sd != LRSC_OK) return sd;
             }
             HIP_TRY(hipMemsetAsync(a.n_req_out, 0, sizeof(uint32_t), ctx->stream));
             e = launch_wp_stitch(a, ctx->stream);

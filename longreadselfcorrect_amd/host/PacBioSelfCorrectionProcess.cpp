@@ -15,7 +15,10 @@ static void orDie(int st, const char* what)
 {
     if(st != LRSC_OK) {
         std::cerr << what << ": " << lrsc_strerror(st) << " (" << lrsc_last_error() << ")\n";
-        exit(EXIT_FAILURE);
+        // called from a worker thread while the reader, the other workers and the post-processor may be inside HIP calls: leave
+        // without running static destructors / the HIP runtime's teardown under them (a plain exit() can hang there)
+        std::cerr.flush(); std::cout.flush();
+        std::_Exit(EXIT_FAILURE);
     }
 }
 
@@ -56,7 +59,9 @@ std::vector<PacBioSelfCorrectionResult> PacBioSelfCorrectionProcess::process_bat
     });
     m_res.resize(n);
     m_pieceOff.resize(std::max<size_t>(m_pieceOff.size(), 2 * n + 16));
-    m_out.resize(std::max<size_t>(m_out.size(), m_bases.size() * 2 + 4096));
+    // the device budgets up to 3 x |read| + 390 per seed for a read's output slot (DP consensuses can outgrow their queries): size for it
+    // at once -- a second call after LRSC_ERR_CAPACITY would run the whole correction again
+    m_out.resize(std::max<size_t>(m_out.size(), m_bases.size() * 3 + 400 * n + 4096));
     uint64_t nPieces = 0, used = 0;
     if(m_params.DebugSeed || m_params.OnlySeed) {
         runWithDiagnostics(items, results, nPieces, used);

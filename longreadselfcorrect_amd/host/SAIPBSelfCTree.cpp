@@ -26,7 +26,10 @@ void orDie(int st, const char* what)
 {
     if(st != LRSC_OK) {
         std::cerr << what << ": " << lrsc_strerror(st) << " (" << lrsc_last_error() << ")\n";
-        exit(EXIT_FAILURE);
+        // called from a worker thread while the reader, the other workers and the post-processor may be inside HIP calls: leave
+        // without running static destructors / the HIP runtime's teardown under them (a plain exit() can hang there)
+        std::cerr.flush(); std::cout.flush();
+        std::_Exit(EXIT_FAILURE);
     }
 }
 

@@ -99,7 +99,9 @@ size_t processSequences(int thread, const std::string& readsFile, const Paramete
     std::condition_variable cv_todo, cv_room, cv_done;
     std::deque<std::unique_ptr<Batch>> todo;
     std::map<size_t, std::unique_ptr<Batch>> done;
-    const size_t max_in_flight = 2 * n_workers + 1;             // filled + in work + finished-but-not-written batches
+    // one batch in work per worker + one being filled + one being written: a batch of the default size is ~1 GB of reads plus as
+    // much in corrected strings, so the count is what bounds host memory (about 2 GB x (workers + 2))
+    const size_t max_in_flight = n_workers + 2;
     size_t in_flight = 0, n_batches = 0;
     bool reading_over = false;
 
