@@ -266,8 +266,8 @@ enum lrsc_read_status {
     LRSC_READ_TOO_LONG = 2,              /* the read's output slot would exceed 4 GB                                     */
     LRSC_READ_FRONTIER_LIMIT = 3,        /* more than 160 terminated lineages / 128 children in one walk                 */
     LRSC_READ_GEOMETRY = 4,              /* seeds overlap / an extension k-mer above 59 or below the idmer size          */
-    LRSC_READ_DP_LIMIT = 5,              /* DP fallback: query beyond the alignment kernel's staging (about 30 kb), or a pile-up beyond
-                                          * its column / consensus capacity                                              */
+    LRSC_READ_DP_LIMIT = 5,              /* DP fallback: a pile-up beyond its column / consensus capacity (a long query is not a
+                                          * limit: alignments beyond the kernel's LDS stage run from a global workspace)   */
     LRSC_READ_OUTPUT_LIMIT = 6,          /* the corrected string outgrew its slot                                        */
     LRSC_READ_INTERNAL = 7               /* FM-extension returned a code the reference treats as impossible (it exits)   */
 };
@@ -279,10 +279,11 @@ enum lrsc_read_status {
 int lrsc_correct_reads(lrsc_ctx* ctx, const char* reads, const uint64_t* read_off, uint32_t n_reads,
                        lrsc_read_result* results, uint64_t* piece_off, uint64_t piece_cap, char* out, uint64_t out_cap,
                        uint64_t* n_pieces, uint64_t* out_used);
-/* The same, for a batch that is already resident on the device (lrsc_batch_create): seeds, the chain of
- * seed-to-seed walks of every read AND the stitching all run on the device (one persistent kernel, one lane
- * per read); only the corrected strings and the counters come back.  lrsc_correct_reads is this call on a
- * temporary batch. */
+/* The same, for a batch that is already resident on the device (lrsc_batch_create): seeds, every seed-to-seed
+ * walk of the batch at once from its predicted source k-mer, one DP round for the failed ones, and a per-read
+ * stitch pass that replays initCorrect's chain and re-queues the walks whose source was not the predicted one
+ * (bit-identical to running the chain in order) -- all on the device; only the corrected strings and the
+ * counters come back.  lrsc_correct_reads is this call on a temporary batch. */
 int lrsc_batch_correct(lrsc_ctx* ctx, lrsc_batch* batch, lrsc_read_result* results, uint64_t* piece_off,
                        uint64_t piece_cap, char* out, uint64_t out_cap, uint64_t* n_pieces, uint64_t* out_used);
 int lrsc_ctx_get_params(const lrsc_ctx* ctx, lrsc_params* out);
