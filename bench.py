@@ -80,6 +80,7 @@ def main():
                          "(default 2 with GPU_MAX_HW_QUEUES=16: measured 32.6 vs 28.8 Mbases/s for 1 part; with the runtime's default of 4 "
                          "hardware queues the streams of the two parts queue behind each other's persistent kernels and 2 parts are slower; "
                          "3 and 4 parts are slower again: the persistent kernels contend for wavefront slots)")
+    ap.add_argument("--no-stagger", action="store_true", help="start the concurrent parts of a step together instead of staggered")
     ap.add_argument("--pipeline", action="store_true",
                     help="several concurrent parts: no join per step (see run_steps); measured 65.8 vs 59.9 corrected Mbases/s, with the Occ-rank "
                          "kernel's own time doubled by the contention")
@@ -205,7 +206,22 @@ def main():
                 for b in groups[g]:
                     b.find_seeds()      # k-mer grid (Occ-rank kernel) + getSeqAttribute + greedy seed scan, all on the device
                 if args.stage != "seeds":
-                    ths = [threading.Thread(target=correct_part, args=(g, j, timed, acc)) for j in range(n_streams)]
+                    # The parts of a step start STAGGERED: part j + 1 starts when part j has reached its DP stage (or is through), so that
+                    # one part's FM-extension (latency-bound, persistent kernels) shares the device with another's DP stage (issue-bound)
+                    # instead of both parts doing the same thing at the same time.
+                    done = [threading.Event() for _ in range(n_streams)]
+
+                    def staggered(j):
+                        if j > 0 and args.stage == "correct" and not args.no_stagger:
+                            base = ctxs[j - 1].stats(K_DP).launches
+                            while not done[j - 1].is_set() and ctxs[j - 1].stats(K_DP).launches == base:
+                                time.sleep(0.005)
+                        try:
+                            correct_part(g, j, timed, acc)
+                        finally:
+                            done[j].set()
+
+                    ths = [threading.Thread(target=staggered, args=(j,)) for j in range(n_streams)]
                     for th in ths: th.start()
                     for th in ths: th.join()
                 if timed and rank == 0:

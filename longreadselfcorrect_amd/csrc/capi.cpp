@@ -1477,7 +1477,7 @@ struct WpScratch {
     DevBuf<WpSlot> d_slots;
     DevBuf<uint64_t> d_sz;                 // three arrays of (entries + 1)
     DevBuf<uint32_t> d_key, d_key_tmp, d_list, d_list_tmp, d_small;   // d_small: plan_stats[4], queue, n_dp_items, n_req
-    DevBuf<WpDpItem> d_items, d_items2;
+    DevBuf<WpDpItem> d_items, d_items2, d_items3;
     hipEvent_t ev_side_t0 = nullptr, ev_side_t1 = nullptr;
     DevBuf<WpRequest> d_req;
     DevBuf<uint8_t> d_prep, d_lane, d_lane_side, d_lane_side2, d_ctx[2];
@@ -1589,6 +1589,11 @@ static int batch_correct_wp(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result* res,
     a.req_out = ws.d_req.p; a.req_cap = n;
     a.out_codes = cs.d_codes_out.p; a.piece_start = cs.d_pieces.p;
     a.auto_dp = (!p.no_dp && p.next_target == 1) ? 1u : 0u;
+    a.general_quorum_pct = 70; a.general_max_wait = 6;
+    size_t dp_split_pct = 100;               // share of the bulk's failed walks in the first DP call when long-gap walks run beside it (100: theirs alone in the second)
+    if(const char* ev = std::getenv("LRSC_WP_DP_SPLIT")) dp_split_pct = (size_t)std::min(100, std::max(10, std::atoi(ev)));
+    if(const char* ev = std::getenv("LRSC_WP_GEN_QUORUM")) a.general_quorum_pct = (uint32_t)std::min(100, std::max(0, std::atoi(ev)));
+    if(const char* ev = std::getenv("LRSC_WP_GEN_WAIT")) a.general_max_wait = (uint32_t)std::max(0, std::atoi(ev));
     a.ctr = ctx->d_ctr;
     if(b->debug_flags & LRSC_DEBUG_WALKS) {
         if(!b->d_walk_log) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_walk_log), b->seed_cap));
@@ -1618,7 +1623,8 @@ static int batch_correct_wp(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result* res,
     }
     if(!ws.ev_ready) HIP_TRY(hipEventCreateWithFlags(&ws.ev_ready, hipEventDisableTiming));
 
-    uint32_t mid_stride = 64;
+    uint32_t mid_stride = 64, long_mode = 0;
+    if(const char* ev = std::getenv("LRSC_WP_LONG_MODE")) long_mode = (uint32_t)std::atoi(ev);
     if(const char* ev = std::getenv("LRSC_WP_MID_STRIDE")) { const int v = std::atoi(ev); if(v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) mid_stride = (uint32_t)v; }
     // One launch of the one-kernel form (wp_extend_kernel: every lane runs both kinds of step) over `count` list entries;
     // stride 64 = one walk per wavefront
@@ -1629,7 +1635,7 @@ static int batch_correct_wp(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result* res,
         // wavefront slots: the side launches (which != 0) and the bulk launch are persistent and share the device, so each gets a share
         // of the resident wavefronts -- a launch that fills every slot first would keep the others out until it ends
         const uint64_t slots = max_lanes / 64;                                        // resident wavefronts of these kernels
-        const uint64_t share = which == 1 ? slots / 2 : which == 2 ? slots / 4 : (reserve_side ? slots - slots / 8 - slots / 4 : slots);
+        const uint64_t share = which == 1 ? slots / 2 : which == 2 ? slots / 4 : (reserve_side ? slots - slots / 2 : slots);
         uint64_t lanes = std::min<uint64_t>(stride == 1 ? (((uint64_t)count + 63) & ~63ull) : count, share * 64 / stride);
         lanes = std::max<uint64_t>(1, std::min<uint64_t>(lanes, (lane_budget / (which ? 4 : 1)) / LL.total));
         if(stride == 1) lanes = std::max<uint64_t>(64, lanes & ~63ull);
@@ -1826,6 +1832,16 @@ static int batch_correct_wp(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result* res,
                     // the walks across long gaps (the first n_mid of the launch order) run thinly spread over wavefronts: a lane-per-walk
                     // wavefront advances at the pace of its slowest lane, and these are thousands of wide steps long.  They follow the bulk
                     // (both launches are persistent and want every wavefront slot).
+                    if(long_mode == 1 && n_mid != 0) {
+                        // beside the bulk from the start, each launch with half of the wavefront slots; one DP round for all failures
+                        e2 = side_begin();
+                        reserve_side = true;
+                        if(e2 == hipSuccess) e2 = extend_range(a, ext_list, nullptr, n_mid, stats[2], ws.side[0], 1, mid_stride);
+                        if(e2 == hipSuccess) e2 = extend_range(a, ext_list + n_mid, nullptr, n_ent - n_mid, std::min(stats[2], kWpPathwSmall), ctx->stream, 0, 1);
+                        reserve_side = false;
+                        if(e2 == hipSuccess) e2 = side_join();
+                        return e2;
+                    }
                     e2 = extend_range(a, ext_list + n_mid, nullptr, n_ent - n_mid, std::min(stats[2], kWpPathwSmall), ctx->stream, 0, 1);
                     if(e2 != hipSuccess || n_mid == 0) return e2;
                     if(p.no_dp) return extend_range(a, ext_list, nullptr, n_mid, stats[2], ctx->stream, 0, mid_stride);
@@ -1870,18 +1886,13 @@ static int batch_correct_wp(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result* res,
 
             // ---- the DP stage for every failed walk of this round (and the explicit requests) ---------------------------------
             uint32_t n_items = 0;
-            auto run_dp = [&](DevBuf<WpDpItem>& d_list, const uint32_t* d_count, uint32_t cap) -> int {
-                uint32_t cnt = 0;
-                HIP_TRY(hipMemcpy(&cnt, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost));
-                if(cnt > cap) return fail(LRSC_ERR_LIMIT, "walk-parallel flow: DP item list overflow");
-                n_items += cnt;
+            // one DP call over `its` (sorted by slot): requests, DpStage, a persistent copy of the consensus buffer, answers into the slots
+            auto dp_call = [&](std::vector<WpDpItem>& its) -> int {
+                const uint32_t cnt = (uint32_t)its.size();
                 if(cnt == 0) return LRSC_OK;
-                items.resize(cnt);
-                HIP_TRY(hipMemcpy(items.data(), d_list.p, (size_t)cnt * sizeof(WpDpItem), hipMemcpyDeviceToHost));
-                std::sort(items.begin(), items.end(), [](const WpDpItem& x, const WpDpItem& y) { return x.slot < y.slot; });
                 reqs.clear();
                 reqs.reserve(cnt);
-                for(const WpDpItem& it : items) {
+                for(const WpDpItem& it : its) {
                     DpRequest q;
                     std::memset(&q, 0, sizeof(q));
                     q.q_off = it.q;                                                          // absolute device address (base pointer 0)
@@ -1903,28 +1914,52 @@ static int batch_correct_wp(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result* res,
                 uint8_t* cons_keep = nullptr;
                 HIP_TRY(ws.persist.alloc(stage.cons_total + 64, &cons_keep));
                 HIP_TRY(hipMemcpyAsync(cons_keep, stage.d_cons.p, stage.cons_total, hipMemcpyDeviceToDevice, ctx->stream));
-                HIP_TRY(hipMemcpyAsync(d_list.p, items.data(), (size_t)cnt * sizeof(WpDpItem), hipMemcpyHostToDevice, ctx->stream));
+                HIP_TRY(ws.d_items3.reserve(cnt));
+                HIP_TRY(hipMemcpyAsync(ws.d_items3.p, its.data(), (size_t)cnt * sizeof(WpDpItem), hipMemcpyHostToDevice, ctx->stream));
                 WpArgs c2 = a;
                 c2.dp_reqs = stage.d_reqs.p; c2.dp_msa = stage.d_msa.p; c2.dp_cons = cons_keep; c2.n_dp = cnt;
-                hipError_t ec = launch_wp_dp_collect(c2, d_list.p, ctx->stream);
+                hipError_t ec = launch_wp_dp_collect(c2, ws.d_items3.p, ctx->stream);
                 if(ec != hipSuccess) return hip_fail(ec, "wp_dp_collect");
-                HIP_TRY(hipStreamSynchronize(ctx->stream));                                  // `items` / the stage's buffers are reused by the next call
+                HIP_TRY(hipStreamSynchronize(ctx->stream));                                  // the stage's buffers are reused by the next call
+                return LRSC_OK;
+            };
+            auto fetch_items = [&](DevBuf<WpDpItem>& d_list, const uint32_t* d_count, uint32_t cap, std::vector<WpDpItem>& out) -> int {
+                uint32_t cnt = 0;
+                HIP_TRY(hipMemcpy(&cnt, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost));
+                if(cnt > cap) return fail(LRSC_ERR_LIMIT, "walk-parallel flow: DP item list overflow");
+                n_items += cnt;
+                out.resize(cnt);
+                if(cnt) HIP_TRY(hipMemcpy(out.data(), d_list.p, (size_t)cnt * sizeof(WpDpItem), hipMemcpyDeviceToHost));
+                std::sort(out.begin(), out.end(), [](const WpDpItem& x, const WpDpItem& y) { return x.slot < y.slot; });
                 return LRSC_OK;
             };
             {
-                const int sd = run_dp(ws.d_items, a.n_dp_items, n_ent);
+                int sd = fetch_items(ws.d_items, a.n_dp_items, n_ent, items);
                 if(sd != LRSC_OK) return sd;
-            }
-            if(long_pending) {
-                // the long-gap walks ran on the side stream while the DP stage answered the bulk's failures: theirs now
-                if(!ws.ev_side_t1) HIP_TRY(hipEventCreate(&ws.ev_side_t1));
-                HIP_TRY(hipEventRecord(ws.ev_side_t1, ws.side[0]));
-                HIP_TRY(hipEventSynchronize(ws.ev_side_t1));
-                float ms = 0.f;
-                HIP_TRY(hipEventElapsedTime(&ms, ws.ev_side_t0, ws.ev_side_t1));
-                ctx->stats[LRSC_K_EXTEND].total_ms += ms;             // overlaps the DP stage: the stage times then add up to more than the wall time
-                long_pending = false;
-                const int sd = run_dp(ws.d_items2, ws.d_small.p + 12, n_long_cap);
+                if(!long_pending) sd = dp_call(items);
+                else {
+                    // The long-gap walks are running on the side stream.  The bulk's failed walks go to the DP stage in two calls: the
+                    // first 60 % now; the rest together with the long walks' failures, which are in by then -- their few, long
+                    // alignments and pile-ups (latency-bound on their own) then overlap the second call's bulk instead of trailing it.
+                    const size_t cut = items.size() * dp_split_pct / 100;
+                    std::vector<WpDpItem> second(items.begin() + (ptrdiff_t)cut, items.end());
+                    items.resize(cut);
+                    sd = dp_call(items);
+                    if(sd != LRSC_OK) return sd;
+                    if(!ws.ev_side_t1) HIP_TRY(hipEventCreate(&ws.ev_side_t1));
+                    HIP_TRY(hipEventRecord(ws.ev_side_t1, ws.side[0]));
+                    HIP_TRY(hipEventSynchronize(ws.ev_side_t1));
+                    float ms = 0.f;
+                    HIP_TRY(hipEventElapsedTime(&ms, ws.ev_side_t0, ws.ev_side_t1));
+                    ctx->stats[LRSC_K_EXTEND].total_ms += ms;             // overlaps the DP stage: the stage times then add up to more than the wall time
+                    long_pending = false;
+                    std::vector<WpDpItem> longs;
+                    sd = fetch_items(ws.d_items2, ws.d_small.p + 12, n_long_cap, longs);
+                    if(sd != LRSC_OK) return sd;
+                    second.insert(second.end(), longs.begin(), longs.end());
+                    std::sort(second.begin(), second.end(), [](const WpDpItem& x, const WpDpItem& y) { return x.slot < y.slot; });
+                    sd = dp_call(second);
+                }
                 if(sd != LRSC_OK) return sd;
             }
             HIP_TRY(hipMemsetAsync(a.n_req_out, 0, sizeof(uint32_t), ctx->stream));

@@ -340,6 +340,8 @@ __global__ __launch_bounds__(64, 2) void wp_extend_kernel(FmIndexDev fm, WpArgs 
     Leaf<P> L;
     uint32_t pw = 0;
     bool fast = false;
+    uint32_t gen_wait = 0;
+    bool want_gen = false;
     // profiling (a.prof): per-lane wall ticks inside the step's regions (Walk::tock slots 0-6), 8 = refill, 9 = finish, 10 = whole loop
     uint64_t pr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t t_refill = 0, t_finish = 0, n_fast = 0;
@@ -371,10 +373,10 @@ __global__ __launch_bounds__(64, 2) void wp_extend_kernel(FmIndexDev fm, WpArgs 
             const P riv[4] = {(P)H->root[0], (P)H->root[1], (P)H->root[2], (P)H->root[3]};
             W.begin_root(riv);
             in_walk = true;
-            fast = false;
+            fast = false; want_gen = false; gen_wait = 0;
             if(prof) t_refill += __builtin_readcyclecounter() - tr0;
         }
-        if(!fast && W.can_fast()) { W.enter_fast(L, pw); fast = true; }
+        if(!fast && !want_gen && W.can_fast()) { W.enter_fast(L, pw); fast = true; }
         int r = 2;
         if(fast) {
             const uint64_t tq = prof ? __builtin_readcyclecounter() : 0;
@@ -382,7 +384,19 @@ __global__ __launch_bounds__(64, 2) void wp_extend_kernel(FmIndexDev fm, WpArgs 
             if(r != 1) fast = false;
             if(prof) { pr[7] += __builtin_readcyclecounter() - tq; if(r == 1) ++n_fast; }
         }
-        if(r == 2) r = W.step() ? 1 : 0;
+        const uint32_t n_fast_now = (uint32_t)__builtin_popcountll(__ballot(r == 1));     // lanes still in the single-leaf regime
+        if(r == 2) {
+            // The general step stalls every lane of the wavefront that is in the single-leaf regime, and costs the same whether
+            // one lane needs it or thirty: a lane that needs it waits (a few iterations at most) until a share of the wavefront's
+            // busy lanes does, so that the wavefront pays for it once for many lanes instead of in every iteration.
+            const uint32_t n_need = (uint32_t)__builtin_popcountll(__ballot(true));
+            const uint32_t n_busy = n_need + n_fast_now;
+            // (one decision for all of them: when the share is there, or when one of them has waited its limit)
+            const bool waited = __ballot(gen_wait >= a.general_max_wait) != 0;
+            if(n_need * 100u < n_busy * a.general_quorum_pct && !waited) { ++gen_wait; want_gen = true; continue; }
+            gen_wait = 0; want_gen = false;
+            r = W.step() ? 1 : 0;
+        }
         if(r == 1) continue;
         in_walk = false;
         const uint64_t tf0 = prof ? __builtin_readcyclecounter() : 0;
