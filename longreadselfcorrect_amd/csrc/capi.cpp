@@ -1240,6 +1240,7 @@ struct DpStage {
         HIP_TRY(hipMemcpyAsync(d_reqs.p, reqs.data(), (size_t)n * sizeof(DpRequest), hipMemcpyHostToDevice, ctx->stream));
         DpPipeArgs a{};
         a.codes = d_query_codes; a.reqs = d_reqs.p; a.n_reqs = n; a.ctr = ctx->d_ctr;
+        { const char* e = std::getenv("LRSC_MSA_BATCH"); a.row_batch = !(e && e[0] == '0'); }
         int st = timed_launch(ctx, LRSC_K_LF, [&]() { return launch_dp_seeds(ctx->fm, a, ctx->stream); });
         if(st != LRSC_OK) return st;
         HIP_TRY(hipMemcpy(reqs.data(), d_reqs.p, (size_t)n * sizeof(DpRequest), hipMemcpyDeviceToHost));
@@ -1262,7 +1263,7 @@ struct DpStage {
                 jobs += r.n_str; sbytes += sb; obytes += ob;
                 if(!too_long[end]) { max1 = std::max(max1, r.lq); max2 = std::max(max2, r.str_cap); }
                 else { max1_long = std::max(max1_long, r.lq); max2_long = std::max(max2_long, r.str_cap); jobs_long += r.n_str; }
-                lds = std::max(lds, dp_msa_lds_bytes(r.w_cols, r.str_cap, r.ops_cap, r.n_str));
+                lds = std::max(lds, dp_msa_lds_bytes(r.w_cols, r.lq, r.str_cap, r.ops_cap, r.n_str));
                 ++end;
             }
             if(jobs >= (1ull << 32)) return fail(LRSC_ERR_UNSUPPORTED, "dp chunk: too many alignments");
@@ -1342,7 +1343,7 @@ struct DpStage {
             for(uint32_t i = 0; i < nc; ++i) todo[i] = i;
             HIP_TRY(d_list.reserve(nc));
             while(!todo.empty()) {
-                static const uint32_t kBuckets[] = {8u << 10, 12u << 10, 16u << 10, 24u << 10, 40u << 10, 80u << 10, 160u << 10, 0xFFFFFFFFu};
+                static const uint32_t kBuckets[] = {8u << 10, 12u << 10, 16u << 10, 20u << 10, 24u << 10, 32u << 10, 40u << 10, 80u << 10, 160u << 10, 0xFFFFFFFFu};
                 const bool force_global = std::getenv("LRSC_MSA_FORCE_GLOBAL") != nullptr;     // test hook for the global-workspace variant
                 // one launch per bucket, all in flight together
                 struct Launch { DpPipeArgs args; };
@@ -1356,7 +1357,7 @@ struct DpStage {
                     uint32_t need_max = 0;
                     for(uint32_t i : todo) {
                         const DpRequest& r = reqs[begin + i];
-                        const uint32_t need = dp_msa_lds_bytes(r.w_cols, r.str_cap, r.ops_cap, r.n_str);
+                        const uint32_t need = dp_msa_lds_bytes(r.w_cols, r.lq, r.str_cap, r.ops_cap, r.n_str);
                         if(need > lo && need <= bk) { all_lists.push_back(i); need_max = std::max(need_max, need); }
                     }
                     lo = bk;
@@ -1408,10 +1409,10 @@ struct DpStage {
                     list.push_back(i);
                 }
                 if(std::getenv("LRSC_CORRECT_PROFILE") && begin == 0) {
-                    double kt = 0, ks = 0, ki = 0, ni = 0, rows = 0;
-                    for(uint32_t i = 0; i < nc; ++i) { kt += mo[i].kc_total; ks += mo[i].kc_stage; ki += mo[i].kc_insert; ni += mo[i].n_insert; rows += mo[i].n_rows; }
-                    std::fprintf(stderr, "[lrsc] msa: %u requests, %.1f rows avg, %.0f insertions avg, per request %.0f k-ticks (staging %.0f, insertions %.0f), redo %zu\n",
-                                 nc, rows / nc, ni / nc, kt / nc, ks / nc, ki / nc, list.size());
+                    double kt = 0, ks = 0, ki = 0, ni = 0, rows = 0, walked = 0;
+                    for(uint32_t i = 0; i < nc; ++i) { kt += mo[i].kc_total; ks += mo[i].kc_stage; ki += mo[i].kc_insert; ni += mo[i].n_insert; rows += mo[i].n_rows; walked += mo[i].pad; }
+                    std::fprintf(stderr, "[lrsc] msa: %u requests, %.1f rows avg (%.2f by the step walk), %.0f insertions avg, per request %.0f k-ticks (staging %.0f, insertions %.0f), redo %zu\n",
+                                 nc, rows / nc, walked / nc, ni / nc, kt / nc, ks / nc, ki / nc, list.size());
                 }
                 todo = list;
                 if(!todo.empty())
@@ -1478,6 +1479,7 @@ struct WpScratch {
     DevBuf<uint64_t> d_sz;                 // three arrays of (entries + 1)
     DevBuf<uint32_t> d_key, d_key_tmp, d_list, d_list_tmp, d_small;   // d_small: plan_stats[4], queue, n_dp_items, n_req
     DevBuf<WpDpItem> d_items, d_items2, d_items3;
+    DevBuf<DevCounters> d_ctr2;
     hipEvent_t ev_side_t0 = nullptr, ev_side_t1 = nullptr;
     DevBuf<WpRequest> d_req;
     DevBuf<uint8_t> d_prep, d_lane, d_lane_side, d_lane_side2, d_ctx[2];
@@ -1875,7 +1877,10 @@ static int batch_correct_wp(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result* res,
                 HIP_TRY(ws.d_items2.reserve(n_mid));
                 WpArgs xl = a;
                 xl.dp_items = ws.d_items2.p; xl.n_dp_items = ws.d_small.p + 12; xl.dp_items_cap = n_mid;
-                xl.ctr = nullptr;                                       // the main stream's launches own the statistics counters
+                // its own statistics counters: the DP stage's timed launches zero and read the ctx's while it runs
+                HIP_TRY(ws.d_ctr2.reserve(kCtrShards));
+                HIP_TRY(hipMemsetAsync(ws.d_ctr2.p, 0, kCtrShards * sizeof(DevCounters), ctx->stream));
+                xl.ctr = ws.d_ctr2.p;
                 HIP_TRY(side_begin());
                 if(!ws.ev_side_t0) HIP_TRY(hipEventCreate(&ws.ev_side_t0));
                 HIP_TRY(hipEventRecord(ws.ev_side_t0, ws.side[0]));
@@ -1952,6 +1957,15 @@ static int batch_correct_wp(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result* res,
                     float ms = 0.f;
                     HIP_TRY(hipEventElapsedTime(&ms, ws.ev_side_t0, ws.ev_side_t1));
                     ctx->stats[LRSC_K_EXTEND].total_ms += ms;             // overlaps the DP stage: the stage times then add up to more than the wall time
+                    {
+                        std::vector<DevCounters> shards(kCtrShards);
+                        HIP_TRY(hipMemcpy(shards.data(), ws.d_ctr2.p, kCtrShards * sizeof(DevCounters), hipMemcpyDeviceToHost));
+                        for(const DevCounters& dcn : shards) {
+                            ctx->stats[LRSC_K_EXTEND].rank_queries += dcn.rank_queries;
+                            ctx->stats[LRSC_K_EXTEND].block_loads += dcn.block_loads;
+                            ctx->stats[LRSC_K_EXTEND].table_loads += dcn.table_loads;
+                        }
+                    }
                     long_pending = false;
                     std::vector<WpDpItem> longs;
                     sd = fetch_items(ws.d_items2, ws.d_small.p + 12, n_long_cap, longs);

@@ -71,6 +71,7 @@ struct DpPipeArgs {
     const uint32_t* req_list;     // optional: run the MSA kernel for these n_list requests only (size buckets, overflow retries)
     uint32_t n_list;
     uint8_t* msa_ws;              // set: state in this global workspace (lds_bytes per workgroup) instead of LDS
+    uint32_t row_batch;           // MSA rows added in wavefront-wide passes (default); 0: the step-by-step walk only
     DevCounters* ctr;
 };
 
@@ -106,7 +107,7 @@ hipError_t launch_dp_seeds(const FmIndexDev& fm, const DpPipeArgs& a, hipStream_
 hipError_t launch_dp_retrieve(const FmIndexDev& fm, const DpPipeArgs& a, hipStream_t stream);
 // wavefront per request: MultipleAlignment::addOverlap for every accepted overlap + calculateBaseConsensus
 hipError_t launch_dp_msa(const DpPipeArgs& a, hipStream_t stream);
-uint32_t dp_msa_lds_bytes(uint32_t w_cols, uint32_t str_cap, uint32_t ops_cap, uint32_t n_str);
+uint32_t dp_msa_lds_bytes(uint32_t w_cols, uint32_t lq, uint32_t str_cap, uint32_t ops_cap, uint32_t n_str);
 // initial column capacity of one multiple alignment: the query plus the gap columns insertions may open
 constexpr uint32_t dp_msa_columns(uint32_t lq) { return 3 * lq + 128; }
 constexpr uint32_t dp_cons_capacity(uint32_t lq) { return 2 * lq + 128; }

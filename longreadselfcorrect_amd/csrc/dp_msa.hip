@@ -12,6 +12,21 @@
 // current template position*; leading_columns of the base row is read once per incoming row (:306), so an
 // insertion in front of base 0 moves the template cursor past a base without consuming a cigar op.
 // Rows are added in retrieval order (source-seed strings, then target-seed strings).
+//
+// One incoming row is added in a few wavefront-wide passes instead of one dependent step per column (a.row_batch,
+// the default).  What makes that possible: in the coordinates the base row has when the row starts, every cigar
+// op's effect is known from prefix counts over the cigar alone --
+//   * an M/D op consumes the next base of the base row; the b-th base sits at bpos[b];
+//   * a run of r I ops in front of base b first fills the G = bpos[b] - bpos[b-1] - 1 gap columns already there
+//     (op i < G lands in column bpos[b-1] + 1 + i), the others each open a new column in front of bpos[b];
+//   * gap columns of the base row the cigar walks over without an I show '-' in the new row;
+// and insertGapBeforeColumn's effect on every other row (leading_columns += 1 when the column is at or before its
+// start, one more padded symbol when strictly inside) only depends on where the new column is in those OLD
+// coordinates, because all earlier insertions of the same row lie at or before it.  So: one pass over the cigar
+// (prefix counts by ballot), the row's symbols scattered into a per-column byte array, one shift of T / cnt / that
+// array by "insertions at or before me", the new columns written, the row's symbols counted in.  Rows that meet the
+// reference's corner cases -- leading insertions in front of base 0 (the cursor quirk above), insertions behind the
+// last base, more than kMaxIns new columns -- take the step-by-step walk, which stays in the kernel.
 #include <hip/hip_runtime.h>
 
 #include "dp_dev.h"
@@ -23,6 +38,8 @@ constexpr uint32_t kGap = 4;
 // per-column counters of A C G T '-' : five 12-bit fields of one 64-bit word (at most 4095 rows)
 using Cnt = unsigned long long;
 constexpr uint32_t kCntBits = 12;
+constexpr uint32_t kMaxIns = 256;         // new columns one row may open on the batched path
+constexpr uint32_t kUnset = 0xFEu;
 __device__ __forceinline__ uint32_t cnt_get(Cnt v, uint32_t sym) { return (uint32_t)(v >> (kCntBits * sym)) & ((1u << kCntBits) - 1u); }
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
@@ -32,13 +49,18 @@ __device__ __forceinline__ uint32_t mbcnt(uint64_t mask)
 }
 } // namespace
 
-uint32_t dp_msa_lds_bytes(uint32_t w_cols, uint32_t str_cap, uint32_t ops_cap, uint32_t n_str)
+uint32_t dp_msa_lds_bytes(uint32_t w_cols, uint32_t lq, uint32_t str_cap, uint32_t ops_cap, uint32_t n_str)
 {
     const uint32_t W = w_cols, E = n_str + 2;
     uint32_t o = 0;
     o += W * (uint32_t)sizeof(Cnt);        // cnt
     o += E * 8;                            // lead, size
+    o += (lq + 2) * 4;                     // bpos
+    o += kMaxIns * 4;                      // insx
+    o += kMaxIns * 2;                      // insg
+    o += kMaxIns;                          // inss
     o += (W + 3) & ~3u;                    // T
+    o += (W + 3) & ~3u;                    // Rw
     o += (str_cap + 3) & ~3u;              // S
     o += (ops_cap + 3) & ~3u;              // ops
     return o;
@@ -58,13 +80,18 @@ __global__ __launch_bounds__(64) void dp_msa_kernel(DpPipeArgs a)
         const DpRequest R = a.reqs[rq];
         const uint64_t t_req0 = __builtin_readcyclecounter();
         uint64_t t_stage = 0, t_ins = 0;
-        uint32_t n_ins = 0;
+        uint32_t n_ins = 0, n_walk = 0;
         const uint32_t W = R.w_cols, E = R.n_str + 2;
         Cnt* cnt = reinterpret_cast<Cnt*>(smem);
         uint32_t* lead = reinterpret_cast<uint32_t*>(smem + W * sizeof(Cnt));
         uint32_t* size = lead + E;
-        uint8_t* T = reinterpret_cast<uint8_t*>(size + E);
-        uint8_t* S = T + ((W + 3) & ~3u);
+        uint32_t* bpos = size + E;                              // padded position of the base row's bases from match[0].start on
+        uint32_t* insx = bpos + (R.lq + 2);                     // new columns of the current row: position in old coordinates,
+        uint16_t* insg = reinterpret_cast<uint16_t*>(insx + kMaxIns);   // rows showing a gap there,
+        uint8_t* inss = reinterpret_cast<uint8_t*>(insg + kMaxIns);     // the row's own symbol
+        uint8_t* T = inss + kMaxIns;
+        uint8_t* Rw = T + ((W + 3) & ~3u);                      // the current row's symbol per base-row position
+        uint8_t* S = Rw + ((W + 3) & ~3u);
         uint8_t* ops = S + ((R.str_cap + 3) & ~3u);
         __syncthreads();
         const uint8_t* q = a.codes + R.q_off;
@@ -109,6 +136,139 @@ __global__ __launch_bounds__(64) void dp_msa_kernel(DpPipeArgs a)
             }
             const uint32_t tl = lead_b;                         // template_leading, read once (:306)
             const uint32_t il = ti + tl;                        // incoming_leading
+            bool batched = false;
+            if(a.row_batch && A.n_ops > 0 && !(ti == 0 && ops[0] == 'I')) {
+                const uint32_t ti0 = ti, m1s = (uint32_t)A.m1s;
+                // bases from ti0 on, and the row's default symbol per position: '-' over a gap column, unset over a base
+                uint32_t nbr = 0;
+                for(uint32_t base = ti0; base < size_b; base += 64) {
+                    const uint32_t i = base + lane;
+                    const bool in = i < size_b;
+                    const bool ng = in && T[i] != kGap;
+                    const uint64_t m = __ballot(ng);
+                    if(ng) { const uint32_t b = nbr + mbcnt(m); if(b < R.lq + 1) bpos[b] = i; }
+                    if(in) Rw[i] = ng ? (uint8_t)kUnset : (uint8_t)kGap;
+                    nbr += (uint32_t)__builtin_popcountll(m);
+                }
+                bool bad = nbr > R.lq + 1;
+                if(lane == 0 && !bad) bpos[nbr] = size_b;
+                __syncthreads();
+                uint32_t md_tot = 0, mi_tot = 0, st_tot = 0, run_carry = 0, last_y = 0;
+                for(uint32_t cb = 0; cb < A.n_ops && !bad; cb += 64) {
+                    const uint32_t j = cb + lane;
+                    const bool valid = j < A.n_ops;
+                    const uint32_t op = valid ? (uint32_t)ops[j] : 0u;
+                    const bool isM = op == 'M', isD = op == 'D', isI = op == 'I';
+                    const uint64_t mMD = __ballot(isM || isD), mMI = __ballot(isM || isI);
+                    const uint32_t brel = md_tot + mbcnt(mMD);
+                    const uint32_t inc = m1s + mi_tot + mbcnt(mMI);
+                    const uint64_t lower = mMD & ((1ull << lane) - 1ull);
+                    const uint32_t run_start = lower ? cb + 64u - (uint32_t)__builtin_clzll(lower) : run_carry;
+                    const uint32_t i_rank = j - run_start;
+                    bool lane_bad = valid && !(isM || isD || isI);
+                    uint32_t y = 0, G = 0;
+                    bool st = false, fill = false;
+                    if((isM || isD) && brel >= nbr) lane_bad = true;
+                    if(isI && brel >= nbr) lane_bad = true;                // behind the last base: the walk's job
+                    if(!lane_bad && valid) {
+                        const uint32_t pb = bpos[brel];
+                        if(isI) {
+                            if(brel > 0) { const uint32_t pp = bpos[brel - 1]; G = pb - pp - 1; y = pp + 1 + i_rank; }
+                            fill = i_rank < G; st = !fill;
+                            if(st) y = pb - 1;                              // last position consumed if the cigar ends here
+                        } else y = pb;
+                    }
+                    const uint64_t mS = __ballot(st);
+                    const uint32_t k = st_tot + mbcnt(mS);
+                    if(st && k >= kMaxIns) lane_bad = true;
+                    if(__ballot(lane_bad)) { bad = true; break; }
+                    const uint32_t sym = (isM || isI) ? (inc < J.s2_len ? (uint32_t)S[inc] : 0u) : kGap;
+                    if(isM || isD || fill) Rw[y] = (uint8_t)sym;
+                    if(st) { insx[k] = y + 1; inss[k] = (uint8_t)sym; }
+                    md_tot += (uint32_t)__builtin_popcountll(mMD);
+                    mi_tot += (uint32_t)__builtin_popcountll(mMI);
+                    st_tot += (uint32_t)__builtin_popcountll(mS);
+                    if(mMD) run_carry = cb + 64u - (uint32_t)__builtin_clzll(mMD);
+                    if(cb + 64 >= A.n_ops) last_y = (uint32_t)__shfl((int)y, (int)((A.n_ops - 1) & 63u));
+                }
+                __syncthreads();
+                if(!bad) {
+                    batched = true;
+                    const uint32_t nin = st_tot;
+                    if(nin) {
+                        const uint64_t t_i0 = __builtin_readcyclecounter();
+                        n_ins += nin;
+                        if(size_b + nin > W || lead_b + size_b + nin > W) { overflow = true; break; }
+                        // rows showing a gap in each new column (strictly inside, old coordinates) ...
+                        for(uint32_t k0 = 0; k0 < nin; k0 += 64) {
+                            const uint32_t k = k0 + lane;
+                            const uint32_t xg = k < nin ? insx[k] + tl : 0u;
+                            uint32_t g = 0;
+                            for(uint32_t e = 0; e < n_el; ++e) { const uint32_t le = lead[e], se = size[e]; g += (le < xg && xg - le < se) ? 1u : 0u; }
+                            if(k < nin) insg[k] = (uint16_t)g;
+                        }
+                        __syncthreads();
+                        // ... then every row takes all of them at once
+                        for(uint32_t e0 = 0; e0 < n_el; e0 += 64) {
+                            const uint32_t e = e0 + lane;
+                            if(e < n_el) {
+                                const uint32_t le = lead[e], se = size[e];
+                                uint32_t before = 0, inside = 0;
+                                for(uint32_t k = 0; k < nin; ++k) {
+                                    const uint32_t xg = insx[k] + tl;
+                                    before += xg <= le ? 1u : 0u;
+                                    inside += (le < xg && xg - le < se) ? 1u : 0u;
+                                }
+                                lead[e] = le + before; size[e] = se + inside;
+                            }
+                        }
+                        // T, cnt and the row's symbols move right by the number of new columns at or before them
+                        const uint32_t x0 = insx[0];
+                        for(uint32_t hi = size_b; hi > x0;) {
+                            const uint32_t n = hi - x0 < 64 ? hi - x0 : 64;
+                            const uint32_t yy = hi - 1 - lane;
+                            Cnt v = 0; uint8_t t = 0, r = 0; uint32_t sh = 0;
+                            if(lane < n) {
+                                v = cnt[yy + tl]; t = T[yy]; r = Rw[yy];
+                                uint32_t lo = 0, hi2 = nin;                  // upper_bound(insx, yy)
+                                while(lo < hi2) { const uint32_t mid = (lo + hi2) >> 1; if(insx[mid] <= yy) lo = mid + 1; else hi2 = mid; }
+                                sh = lo;
+                            }
+                            __syncthreads();
+                            if(lane < n && sh) { cnt[yy + sh + tl] = v; T[yy + sh] = t; Rw[yy + sh] = r; }
+                            __syncthreads();
+                            hi -= n;
+                        }
+                        for(uint32_t k0 = 0; k0 < nin; k0 += 64) {
+                            const uint32_t k = k0 + lane;
+                            if(k < nin) {
+                                const uint32_t np = insx[k] + k;
+                                T[np] = (uint8_t)kGap; Rw[np] = inss[k];
+                                cnt[np + tl] = (Cnt)((uint32_t)insg[k] + 1u) << (kCntBits * kGap);
+                            }
+                        }
+                        size_b += nin;
+                        __syncthreads();
+                        t_ins += __builtin_readcyclecounter() - t_i0;
+                    }
+                    const uint32_t nout = last_y + 1 - ti0 + nin;
+                    if(nout > W) { overflow = true; break; }
+                    for(uint32_t z0 = 0; z0 < nout; z0 += 64) {
+                        const uint32_t z = z0 + lane;
+                        if(z < nout) {
+                            const uint32_t sym = Rw[ti0 + z];
+                            if(sym <= kGap && ti0 + z + tl < W) cnt[ti0 + z + tl] += 1ull << (kCntBits * sym);
+                        }
+                    }
+                    __syncthreads();
+                    if(n_el >= E) { overflow = true; break; }
+                    if(lane == 0) { lead[n_el] = il; size[n_el] = nout; }
+                    ++n_el;
+                    __syncthreads();
+                }
+            }
+            if(batched) continue;
+            ++n_walk;
             // The cigar walk is one dependent step per column.  To keep a step at register speed the next 64 bytes of the
             // base row, of the cigar and of the incoming string sit one per lane in a register and are picked with
             // v_readlane; the output symbols are collected the same way and counted into their columns 64 at a time.
@@ -241,7 +401,7 @@ __global__ __launch_bounds__(64) void dp_msa_kernel(DpPipeArgs a)
         }
         if(lane == 0) {
             DpMsaOut o;
-            o.n_rows = n_rows; o.cons_len = overflow ? 0 : cons_len; o.error = !overflow ? 0u : cons_len == 0xFFFFFFFFu ? 2u : 1u; o.pad = 0;
+            o.n_rows = n_rows; o.cons_len = overflow ? 0 : cons_len; o.error = !overflow ? 0u : cons_len == 0xFFFFFFFFu ? 2u : 1u; o.pad = n_walk;
             o.kc_total = (uint32_t)((__builtin_readcyclecounter() - t_req0) >> 10); o.kc_stage = (uint32_t)(t_stage >> 10);
             o.kc_insert = (uint32_t)(t_ins >> 10); o.n_insert = n_ins;
             a.msa[rq] = o;
