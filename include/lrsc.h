@@ -324,7 +324,8 @@ typedef struct lrsc_msa_result {
     uint32_t n_rows;             /* MultipleAlignment::getNumRows(): 1 + accepted overlaps                    */
     uint32_t n_retrieved;        /* strings LF-walked out of the index                                         */
     uint32_t cons_len;           /* consensus at arena + cons_off                                              */
-    uint32_t pad;
+    uint32_t rows_by_step_walk;  /* diagnostic: rows the kernel added one cigar step at a time (corner cases, or
+                                    all of them with LRSC_MSA_BATCH=0) instead of in wavefront-wide passes          */
     uint64_t cons_off;
 } lrsc_msa_result;
 int lrsc_dp_consensus(lrsc_ctx* ctx, const char* seq, uint64_t seq_len, const lrsc_msa_query* queries, uint32_t n,

@@ -98,7 +98,7 @@ class MsaQuery(C.Structure):
 
 
 class MsaResult(C.Structure):
-    _fields_ = [("n_rows", C.c_uint32), ("n_retrieved", C.c_uint32), ("cons_len", C.c_uint32), ("pad", C.c_uint32),
+    _fields_ = [("n_rows", C.c_uint32), ("n_retrieved", C.c_uint32), ("cons_len", C.c_uint32), ("rows_by_step_walk", C.c_uint32),
                 ("cons_off", C.c_uint64)]
 
 
@@ -432,6 +432,7 @@ class Ctx:
         arena = C.create_string_buffer(cap)
         used = C.c_uint64()
         self.api.check(self.api.lib.lrsc_dp_consensus(self.h, seq, len(seq), qs, n, res, arena, cap, C.byref(used)), "lrsc_dp_consensus")
+        self.msa_rows_by_step_walk = sum(r.rows_by_step_walk for r in res)      # diagnostic of the last call
         return [(r.n_rows, arena.raw[r.cons_off: r.cons_off + r.cons_len].decode(), r.n_retrieved) for r in res]
 
     def extend_walks(self, walks):

@@ -2211,7 +2211,7 @@ extern "C" int lrsc_dp_consensus(lrsc_ctx* ctx, const char* seq, uint64_t seq_le
     uint64_t used = 0;
     for(uint32_t i = 0; i < n; ++i) {
         if(mo[i].error) return fail(LRSC_ERR_LIMIT, "msa: column capacity exceeded");
-        results[i].n_rows = mo[i].n_rows; results[i].n_retrieved = reqs[i].n_str; results[i].cons_len = mo[i].cons_len; results[i].pad = 0;
+        results[i].n_rows = mo[i].n_rows; results[i].n_retrieved = reqs[i].n_str; results[i].cons_len = mo[i].cons_len; results[i].rows_by_step_walk = mo[i].pad;
         results[i].cons_off = used;
         if(arena && used + mo[i].cons_len <= arena_cap)
             for(uint32_t t = 0; t < mo[i].cons_len; ++t) arena[used + t] = "ACGT"[cons[reqs[i].cons_off + t] & 3u];

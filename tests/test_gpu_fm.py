@@ -514,18 +514,24 @@ def _dp_queries(rng, ds, n):
     return out
 
 
-@pytest.mark.parametrize("cov,force_global", [(90, False), (20, False), (90, True)])
-def test_dp_consensus_matches_oracle(api, gpu_index, oracle, small_ds, cov, force_global, monkeypatch):
+@pytest.mark.parametrize("cov,force_global,row_batch", [(90, False, True), (20, False, True), (90, True, True),
+                                                        (90, False, False), (20, True, False)])
+def test_dp_consensus_matches_oracle(api, gpu_index, oracle, small_ds, cov, force_global, row_batch, monkeypatch):
     """retrieveStr + extendMatch + MultipleAlignment + calculateBaseConsensus: rows, retrieved-string count and the
-    consensus string, bit-identical to the oracle's line-by-line restatement of LongReadOverlap.cpp / multiple_alignment.cpp."""
+    consensus string, bit-identical to the oracle's line-by-line restatement of LongReadOverlap.cpp / multiple_alignment.cpp.
+    row_batch False keeps the kernel's step-by-step cigar walk (the path the corner-case rows take) under test."""
     if force_global:
         monkeypatch.setenv("LRSC_MSA_FORCE_GLOBAL", "1")       # the pile-up state in global memory instead of LDS (very wide pile-ups)
+    if not row_batch:
+        monkeypatch.setenv("LRSC_MSA_BATCH", "0")
     rng = np.random.default_rng(1234 + cov)
     qs = _dp_queries(rng, small_ds, 60)
     p = api.params_default(5, cov)
     ctx = gpu_index.ctx(p, 0)
     got = ctx.dp_consensus(qs)
+    walked, added = ctx.msa_rows_by_step_walk, sum(g[0] - 1 for g in got)
     ctx.close()
+    assert walked == added if not row_batch else walked * 10 < added      # the switch selects the path it says
     ob, orb = oracle.bwt_load(small_ds.prefix + ".bwt"), oracle.bwt_load(small_ds.prefix + ".rbwt")
     n_multi = 0
     for (q, k, mo, mi, mc), g in zip(qs, got):
