@@ -81,6 +81,9 @@ def main():
                          "hardware queues the streams of the two parts queue behind each other's persistent kernels and 2 parts are slower; "
                          "3 and 4 parts are slower again: the persistent kernels contend for wavefront slots)")
     ap.add_argument("--no-stagger", action="store_true", help="start the concurrent parts of a step together instead of staggered")
+    ap.add_argument("--stagger-on", choices=["align", "dp"], default="align",
+                    help="what part j waits for in part j-1: its first extendMatch launch done (align), or its DP stage entered (dp: the "
+                         "LF-walk launch in front of it)")
     ap.add_argument("--pipeline", action="store_true",
                     help="several concurrent parts: no join per step (see run_steps); measured 65.8 vs 59.9 corrected Mbases/s, with the Occ-rank "
                          "kernel's own time doubled by the contention")
@@ -213,8 +216,9 @@ def main():
 
                     def staggered(j):
                         if j > 0 and args.stage == "correct" and not args.no_stagger:
-                            base = ctxs[j - 1].stats(K_DP).launches
-                            while not done[j - 1].is_set() and ctxs[j - 1].stats(K_DP).launches == base:
+                            kq = K_DP if args.stagger_on == "align" else K_LF
+                            base = ctxs[j - 1].stats(kq).launches
+                            while not done[j - 1].is_set() and ctxs[j - 1].stats(kq).launches == base:
                                 time.sleep(0.005)
                         try:
                             correct_part(g, j, timed, acc)

@@ -1199,6 +1199,7 @@ struct DpStage {
     DevBuf<DpAlignOut> d_align;
     DevBuf<uint32_t> d_list;
     DevBuf<uint8_t> d_msa_ws, d_seq_ws;
+    DevBuf<uint32_t> d_msa_ctr;
     uint64_t cons_total = 0, n_strings = 0;
     // the MSA size buckets of a round run concurrently on side streams (each bucket's launch ends with a tail of a few long
     // pile-ups; serialised, those tails cost more than the work)
@@ -1362,6 +1363,13 @@ struct DpStage {
                     }
                     lo = bk;
                     if(all_lists.size() == first) continue;
+                    // a launch hands its requests to the wavefronts round-robin: the biggest pile-ups (rows x columns) first, so that the
+                    // launch does not end on one of them
+                    std::sort(all_lists.begin() + (std::ptrdiff_t)first, all_lists.end(), [&](uint32_t x, uint32_t y) {
+                        const DpRequest& rx = reqs[begin + x]; const DpRequest& ry = reqs[begin + y];
+                        const uint64_t wx = (uint64_t)rx.lq * rx.n_str, wy = (uint64_t)ry.lq * ry.n_str;
+                        return wx != wy ? wx > wy : x < y;
+                    });
                     Launch L;
                     L.args = c;
                     L.args.req_list = reinterpret_cast<const uint32_t*>(first);          // offset for now, pointer after the upload
@@ -1376,9 +1384,13 @@ struct DpStage {
                 HIP_TRY(d_list.reserve(std::max<size_t>(all_lists.size(), 1)));
                 if(ws_bytes) HIP_TRY(d_msa_ws.reserve(ws_bytes));
                 HIP_TRY(hipMemcpyAsync(d_list.p, all_lists.data(), all_lists.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-                for(Launch& L : launches) {
+                HIP_TRY(d_msa_ctr.reserve(std::max<size_t>(launches.size(), 16)));
+                HIP_TRY(hipMemsetAsync(d_msa_ctr.p, 0, launches.size() * sizeof(uint32_t), ctx->stream));
+                for(size_t j = 0; j < launches.size(); ++j) {
+                    Launch& L = launches[j];
                     L.args.req_list = d_list.p + reinterpret_cast<size_t>(L.args.req_list);
                     if(L.args.msa_ws) L.args.msa_ws = d_msa_ws.p;
+                    L.args.work_ctr = d_msa_ctr.p + j;
                 }
                 for(int i = 0; i < kSide; ++i) {
                     if(!side[i]) HIP_TRY(hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking));

@@ -71,6 +71,7 @@ struct DpPipeArgs {
     const uint32_t* req_list;     // optional: run the MSA kernel for these n_list requests only (size buckets, overflow retries)
     uint32_t n_list;
     uint8_t* msa_ws;              // set: state in this global workspace (lds_bytes per workgroup) instead of LDS
+    uint32_t* work_ctr;           // optional, zeroed: the MSA kernel's wavefronts take their next request from it (after their first)
     uint32_t row_batch;           // MSA rows added in wavefront-wide passes (default); 0: the step-by-step walk only
     DevCounters* ctr;
 };

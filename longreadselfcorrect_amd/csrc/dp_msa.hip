@@ -61,7 +61,7 @@ uint32_t dp_msa_lds_bytes(uint32_t w_cols, uint32_t lq, uint32_t str_cap, uint32
     o += kMaxIns;                          // inss
     o += (W + 3) & ~3u;                    // T
     o += (W + 3) & ~3u;                    // Rw
-    o += (str_cap + 3) & ~3u;              // S
+    o += (str_cap + 7) & ~3u;              // S (staged by dwords from the aligned address below the string)
     o += (ops_cap + 3) & ~3u;              // ops
     return o;
 }
@@ -75,8 +75,14 @@ __global__ __launch_bounds__(64) void dp_msa_kernel(DpPipeArgs a)
     uint8_t* smem = GLOBAL ? a.msa_ws + (uint64_t)blockIdx.x * a.lds_bytes : smem_lds;
     const uint32_t lane = lane_id();
     const uint32_t n_work = a.req_list ? a.n_list : a.n_reqs;
-    for(uint32_t wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+    for(uint32_t wi = blockIdx.x; wi < n_work;) {
         const uint32_t rq = a.req_list ? a.req_list[wi] : wi;
+        // the next request: round-robin, or (work_ctr) whichever is next when this wavefront is done -- the lists come biggest first
+        uint32_t wi_next = wi + gridDim.x;
+        if(a.work_ctr) {
+            if(lane == 0) wi_next = gridDim.x + atomicAdd(a.work_ctr, 1u);
+            wi_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)wi_next);
+        }
         const DpRequest R = a.reqs[rq];
         const uint64_t t_req0 = __builtin_readcyclecounter();
         uint64_t t_stage = 0, t_ins = 0;
@@ -91,8 +97,8 @@ __global__ __launch_bounds__(64) void dp_msa_kernel(DpPipeArgs a)
         uint8_t* inss = reinterpret_cast<uint8_t*>(insg + kMaxIns);     // the row's own symbol
         uint8_t* T = inss + kMaxIns;
         uint8_t* Rw = T + ((W + 3) & ~3u);                      // the current row's symbol per base-row position
-        uint8_t* S = Rw + ((W + 3) & ~3u);
-        uint8_t* ops = S + ((R.str_cap + 3) & ~3u);
+        uint8_t* Sbase = Rw + ((W + 3) & ~3u);
+        uint8_t* ops = Sbase + ((R.str_cap + 7) & ~3u);              // the cigar as the alignment kernel wrote it: last op first
         __syncthreads();
         const uint8_t* q = a.codes + R.q_off;
         for(uint32_t c = lane; c < W; c += 64) {
@@ -104,16 +110,30 @@ __global__ __launch_bounds__(64) void dp_msa_kernel(DpPipeArgs a)
         uint32_t lead_b = 0, size_b = R.lq, n_el = 0, n_rows = 1;
         bool overflow = false;
 
+        DpAlignOut A_next{};
+        DpJob J_next{};
+        if(R.n_str) { A_next = a.align[R.job_first]; J_next = a.jobs[R.job_first]; }
         for(uint32_t s = 0; s < R.n_str && !overflow; ++s) {
-            const DpAlignOut A = a.align[R.job_first + s];
+            const DpAlignOut A = A_next;
+            const DpJob J = J_next;
+            if(s + 1 < R.n_str) { A_next = a.align[R.job_first + s + 1]; J_next = a.jobs[R.job_first + s + 1]; }   // in flight during this row
             if(!A.accept) continue;
-            const DpJob J = a.jobs[R.job_first + s];
             ++n_rows;
             const uint64_t t_s0 = __builtin_readcyclecounter();
             __syncthreads();
-            for(uint32_t i = lane; i < J.s2_len; i += 64) S[i] = a.strings[J.s2_off + i];
-            for(uint32_t i = lane; i < A.n_ops; i += 64) ops[i] = a.ops[J.ops_off + A.n_ops - 1 - i];      // forward order
+            // staged four bytes per lane; the string from the aligned address at or below its start
+            const uint32_t so = (uint32_t)(J.s2_off & 3u);
+            const uint8_t* S = Sbase + so;
+            {
+                const uint32_t* src = reinterpret_cast<const uint32_t*>(a.strings + (J.s2_off - so));
+                uint32_t* dst = reinterpret_cast<uint32_t*>(Sbase);
+                for(uint32_t i = lane, n = (so + J.s2_len + 3) >> 2; i < n; i += 64) dst[i] = src[i];
+                const uint32_t* osrc = reinterpret_cast<const uint32_t*>(a.ops + J.ops_off);
+                uint32_t* odst = reinterpret_cast<uint32_t*>(ops);
+                for(uint32_t i = lane, n = (A.n_ops + 3) >> 2; i < n; i += 64) odst[i] = osrc[i];
+            }
             __syncthreads();
+            const uint32_t op_last = A.n_ops - 1;                         // forward op j = ops[op_last - j]
             t_stage += __builtin_readcyclecounter() - t_s0;
 
             // getPaddedPositionOfBase(match[0].start): index in T of the match0_start-th non-gap symbol
@@ -137,7 +157,7 @@ __global__ __launch_bounds__(64) void dp_msa_kernel(DpPipeArgs a)
             const uint32_t tl = lead_b;                         // template_leading, read once (:306)
             const uint32_t il = ti + tl;                        // incoming_leading
             bool batched = false;
-            if(a.row_batch && A.n_ops > 0 && !(ti == 0 && ops[0] == 'I')) {
+            if(a.row_batch && A.n_ops > 0 && !(ti == 0 && ops[op_last] == 'I')) {
                 const uint32_t ti0 = ti, m1s = (uint32_t)A.m1s;
                 // bases from ti0 on, and the row's default symbol per position: '-' over a gap column, unset over a base
                 uint32_t nbr = 0;
@@ -157,7 +177,7 @@ __global__ __launch_bounds__(64) void dp_msa_kernel(DpPipeArgs a)
                 for(uint32_t cb = 0; cb < A.n_ops && !bad; cb += 64) {
                     const uint32_t j = cb + lane;
                     const bool valid = j < A.n_ops;
-                    const uint32_t op = valid ? (uint32_t)ops[j] : 0u;
+                    const uint32_t op = valid ? (uint32_t)ops[op_last - j] : 0u;
                     const bool isM = op == 'M', isD = op == 'D', isI = op == 'I';
                     const uint64_t mMD = __ballot(isM || isD), mMI = __ballot(isM || isI);
                     const uint32_t brel = md_tot + mbcnt(mMD);
@@ -279,7 +299,7 @@ __global__ __launch_bounds__(64) void dp_msa_kernel(DpPipeArgs a)
                 return (uint32_t)__builtin_amdgcn_readlane((int)Tw, (int)(i - tb));
             };
             auto getO = [&](uint32_t i) -> uint32_t {
-                if(i - ob >= 64u) { ob = i; const uint32_t j = i + lane; Ow = j < A.n_ops ? (uint32_t)ops[j] : 0u; }
+                if(i - ob >= 64u) { ob = i; const uint32_t j = i + lane; Ow = j < A.n_ops ? (uint32_t)ops[op_last - j] : 0u; }
                 return (uint32_t)__builtin_amdgcn_readlane((int)Ow, (int)(i - ob));
             };
             auto getS = [&](uint32_t i) -> uint32_t {
@@ -406,6 +426,7 @@ __global__ __launch_bounds__(64) void dp_msa_kernel(DpPipeArgs a)
             o.kc_insert = (uint32_t)(t_ins >> 10); o.n_insert = n_ins;
             a.msa[rq] = o;
         }
+        wi = wi_next;
     }
 }
 
