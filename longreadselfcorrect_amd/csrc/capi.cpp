@@ -1639,17 +1639,23 @@ static int batch_correct_wp(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result* res,
 
     uint32_t mid_stride = 64, long_mode = 0;
     if(const char* ev = std::getenv("LRSC_WP_LONG_MODE")) long_mode = (uint32_t)std::atoi(ev);
+    uint32_t leaves_in_lds = 0;                      // measured: 77.5-77.7 vs 79.1-80.3 corrected Mbases/s with the leaves in LDS (the DP stage beside it wants the LDS)
+    if(const char* ev = std::getenv("LRSC_WP_LEAVES_LDS")) leaves_in_lds = std::atoi(ev) != 0;
+    uint32_t long_first_div = 8;
+    if(const char* ev = std::getenv("LRSC_WP_SIDE_DIV")) long_first_div = (uint32_t)std::min(64, std::max(2, std::atoi(ev)));
     if(const char* ev = std::getenv("LRSC_WP_MID_STRIDE")) { const int v = std::atoi(ev); if(v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) mid_stride = (uint32_t)v; }
     // One launch of the one-kernel form (wp_extend_kernel: every lane runs both kinds of step) over `count` list entries;
     // stride 64 = one walk per wavefront
     bool reserve_side = false;
+    uint64_t side_div = 2;                                                   // the side launch's share of the wavefront slots: 1 / side_div
     auto extend_range = [&](WpArgs x, const uint32_t* list, const WpRequest* reqs, uint32_t count, uint32_t pathw, hipStream_t st, int which, uint32_t stride) -> hipError_t {
         if(count == 0) return hipSuccess;
         const WpLaneLayout LL = wp_lane_layout(lbytes, pathw);
         // wavefront slots: the side launches (which != 0) and the bulk launch are persistent and share the device, so each gets a share
         // of the resident wavefronts -- a launch that fills every slot first would keep the others out until it ends
         const uint64_t slots = max_lanes / 64;                                        // resident wavefronts of these kernels
-        const uint64_t share = which == 1 ? slots / 2 : which == 2 ? slots / 4 : (reserve_side ? slots - slots / 2 : slots);
+        const uint64_t side_part = std::max<uint64_t>(1, slots / side_div);
+        const uint64_t share = which == 1 ? side_part : which == 2 ? slots / 4 : (reserve_side ? slots - side_part : slots);
         uint64_t lanes = std::min<uint64_t>(stride == 1 ? (((uint64_t)count + 63) & ~63ull) : count, share * 64 / stride);
         lanes = std::max<uint64_t>(1, std::min<uint64_t>(lanes, (lane_budget / (which ? 4 : 1)) / LL.total));
         if(stride == 1) lanes = std::max<uint64_t>(64, lanes & ~63ull);
@@ -1658,6 +1664,7 @@ static int batch_correct_wp(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result* res,
         if(e2 != hipSuccess) return e2;
         x.list = list; x.reqs = reqs; x.n_list = count;
         x.lane_ws = buf.p; x.lane_ws_bytes = LL.total; x.lane_pathw = pathw; x.n_lanes = (uint32_t)lanes; x.lane_stride = stride;
+        x.leaves_in_lds = leaves_in_lds;
         x.queue = ws.d_small.p + 8 + which;
         e2 = hipMemsetAsync(x.queue, 0, sizeof(uint32_t), st);
         if(e2 != hipSuccess) return e2;
@@ -1837,10 +1844,36 @@ static int batch_correct_wp(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result* res,
                 ext_list = ws.d_list.p;
                 n_mid = stats[0]; n_big = stats[1];
             }
+            // long_mode 2: the long-gap walks start FIRST, on the side stream with a small share of the wavefront slots (their launch is as
+            // long as its longest single walk, not as its walk count), the bulk beside them with the rest; the bulk's failures go to the
+            // DP stage while the long walks are still running, theirs in a second call
+            const bool long_first = round == 0 && long_mode == 2 && !use_sched && !p.no_dp && n_mid != 0 && n_mid < n_ent;
+            WpArgs xl_first = a;
+            if(long_first) {
+                HIP_TRY(ws.d_items2.reserve(n_mid));
+                xl_first.dp_items = ws.d_items2.p; xl_first.n_dp_items = ws.d_small.p + 12; xl_first.dp_items_cap = n_mid;
+                HIP_TRY(ws.d_ctr2.reserve(kCtrShards));
+                HIP_TRY(hipMemsetAsync(ws.d_ctr2.p, 0, kCtrShards * sizeof(DevCounters), ctx->stream));
+                xl_first.ctr = ws.d_ctr2.p;
+                if(!ws.ev_side_t0) HIP_TRY(hipEventCreate(&ws.ev_side_t0));
+            }
             const int st = timed_launch(ctx, LRSC_K_EXTEND, [&]() -> hipError_t {
                 hipError_t e2 = launch_wp_prepare(ctx->fm, a, ctx->stream);
                 if(e2 == hipSuccess) e2 = launch_wp_begin(ctx->fm, a, ctx->stream);
                 if(e2 != hipSuccess) return e2;
+                if(long_first) {
+                    e2 = side_begin();
+                    if(e2 == hipSuccess) e2 = hipEventRecord(ws.ev_side_t0, ws.side[0]);
+                    side_div = long_first_div;
+                    reserve_side = true;
+                    if(e2 == hipSuccess) e2 = extend_range(xl_first, ext_list, nullptr, n_mid, stats[2], ws.side[0], 1, mid_stride);
+                    if(e2 == hipSuccess) e2 = extend_range(a, ext_list + n_mid, nullptr, n_ent - n_mid, std::min(stats[2], kWpPathwSmall), ctx->stream, 0, 1);
+                    reserve_side = false;
+                    side_div = 2;
+                    n_long_cap = n_mid;
+                    long_pending = e2 == hipSuccess;
+                    return e2;
+                }
                 if(!use_sched) {
                     if(round != 0) return extend_range(a, a.list, a.reqs, n_ent, std::max(stats[2], 1u), ctx->stream, 0, n_ent <= 16384 ? 64u : n_ent <= 65536 ? 16u : 1u);
                     // the walks across long gaps (the first n_mid of the launch order) run thinly spread over wavefronts: a lane-per-walk

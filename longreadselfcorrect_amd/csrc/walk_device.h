@@ -8,6 +8,12 @@
 #include "introsort_emul.h"
 #include "rank_device.h"
 
+// The big sequential pieces of the walk are calls, not inline copies (code size; register budget per piece).  An experiment build can
+// define this empty (-DLRSC_WALK_NOINLINE=) to let a kernel's launch bounds govern the whole call tree.
+#ifndef LRSC_WALK_NOINLINE
+#define LRSC_WALK_NOINLINE __noinline__
+#endif
+
 namespace lrsc {
 
 constexpr uint64_t kNoKey = ~0ull;
@@ -85,7 +91,7 @@ __device__ __forceinline__ void ktab_entry(const FmIndexDev& fm, int t, uint32_t
     }
 }
 template <bool WIDE>
-__device__ __noinline__ bool prepare_all_from_tables(const FmIndexDev& fm, const uint8_t* __restrict__ q, uint32_t Lq, uint32_t trg0, uint32_t seedk,
+__device__ LRSC_WALK_NOINLINE bool prepare_all_from_tables(const FmIndexDev& fm, const uint8_t* __restrict__ q, uint32_t Lq, uint32_t trg0, uint32_t seedk,
                                                      uint32_t mink, SortItem* it9f, SortItem* it9r, uint8_t* flags5, typename Lay<WIDE>::pos_t* term)
 {
     using P = typename Lay<WIDE>::pos_t;
@@ -230,7 +236,7 @@ struct Walk {
         n_rank += st.n_rank; n_blk += st.n_blk;
         flo = st.fwd.lo; fhi = st.fwd.hi; rlo = st.rvc.lo; rhi = st.rvc.hi;
     }
-    __device__ __noinline__ void find_suffix(Leaf<P>& lf, uint32_t l)
+    __device__ LRSC_WALK_NOINLINE void find_suffix(Leaf<P>& lf, uint32_t l)
     {
         P a, b, c, d;
         find_suffix_v(lf.suf_lo, lf.suf_hi, l, a, b, c, d);
@@ -239,7 +245,7 @@ struct Walk {
 
     // refineSAInterval (.cpp:355-369).  The leaves' searches are independent: four run side by side, so that a dependent rank step
     // of one leaf waits together with those of three others (a lane walks its frontier leaf by leaf otherwise)
-    __device__ __noinline__ void refineSAInterval(Leaf<P>* leaves, uint32_t n, uint64_t newKmerSize)
+    __device__ LRSC_WALK_NOINLINE void refineSAInterval(Leaf<P>* leaves, uint32_t n, uint64_t newKmerSize)
     {
         const uint32_t l = (uint32_t)newKmerSize;
         for(uint32_t i0 = 0; i0 < n; i0 += 4) {
@@ -326,7 +332,7 @@ struct Walk {
         f = upd(sR, b, f);                           // no validity check here (.cpp:317-318)
         r = upd(sF, 3u - b, r);
     }
-    __device__ __noinline__ uint64_t SelectFreqsOfrange(uint64_t LowerBound, uint64_t UpperBound, Leaf<P>* leaves, uint32_t n)
+    __device__ LRSC_WALK_NOINLINE uint64_t SelectFreqsOfrange(uint64_t LowerBound, uint64_t UpperBound, Leaf<P>* leaves, uint32_t n)
     {
         int tempmaxfmfreqs = 0;
         const uint32_t U = (uint32_t)UpperBound, Lw = (uint32_t)LowerBound;
@@ -559,7 +565,7 @@ struct Walk {
     }
 
     // ---- isSupportedByNewSeed (.cpp:566-635) ------------------------------------------------------------------
-    __device__ __noinline__ bool isSupportedByNewSeed(Leaf<P>& nd, uint64_t smallSeedIdx, uint64_t largeSeedIdx)
+    __device__ LRSC_WALK_NOINLINE bool isSupportedByNewSeed(Leaf<P>& nd, uint64_t smallSeedIdx, uint64_t largeSeedIdx)
     {
         return seed_support_core(nd, smallSeedIdx, largeSeedIdx);
     }
@@ -672,7 +678,7 @@ struct Walk {
     }
 
     // ---- isTerminated for one leaf (.cpp:825-878); path given as (words, len) + optional extra char ------------
-    __device__ __noinline__ void terminated_leaf(Leaf<P>& lf, const uint32_t* pw, uint32_t plen, int extra)
+    __device__ LRSC_WALK_NOINLINE void terminated_leaf(Leaf<P>& lf, const uint32_t* pw, uint32_t plen, int extra)
     {
         const bool fvalid = lf.flo <= lf.fhi, rvalid = lf.rlo <= lf.rhi;
         // A non-empty interval of a k-mer K lies inside the interval of a k-mer w with |w| <= |K| only if K ends with w (fwd strand:
@@ -728,7 +734,7 @@ struct Walk {
 
     // The constructor's per-walk tables that stay fixed during the walk (.cpp:90-94,127-152 after the bulk look-ups of
     // prepare_offset): the interval "trees" as sorted k-mer chains, the 5-mer chains, the isTerminated filter.
-    __device__ __noinline__ void begin_static()
+    __device__ LRSC_WALK_NOINLINE void begin_static()
     {
         // --- interval "trees": compact the valid 9-mer entries (emplace_back order), introsort, chain by k-mer ---
         auto build9 = [&](SortItem* it, uint32_t n_all, uint16_t* head, uint16_t* next) -> uint32_t {
@@ -778,7 +784,7 @@ struct Walk {
 
     // --- root (initialRootNode, .cpp:108-124; leafInfo ctor, .h:156-171).  root_iv: the root k-mer's bi-interval {fwd.lo,
     //     fwd.hi, rvc.lo, rvc.hi} when a preparation pass has already searched it, nullptr to search it here ---
-    __device__ __noinline__ void begin_root(const P* root_iv)
+    __device__ LRSC_WALK_NOINLINE void begin_root(const P* root_iv)
     {
         ring_free = 0xFFFFFFFEu; path_free = 0xFFFFFFFEu;
         Leaf<P>& root = cur[0];
@@ -807,7 +813,7 @@ struct Walk {
         ended = false;
     }
 
-    __device__ __noinline__ void begin()
+    __device__ LRSC_WALK_NOINLINE void begin()
     {
         const uint64_t t_run0 = __builtin_readcyclecounter();
         begin_static();
@@ -996,7 +1002,7 @@ struct Walk {
         }
     }
 
-    __device__ __noinline__ int finish(uint32_t* out_len, uint32_t* out_words, uint32_t* out_match_i)
+    __device__ LRSC_WALK_NOINLINE int finish(uint32_t* out_len, uint32_t* out_words, uint32_t* out_match_i)
     {
         if(error) return error;
         // --- findTheBestPath (.cpp:214-236) ---

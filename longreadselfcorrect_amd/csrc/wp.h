@@ -157,6 +157,7 @@ struct WpArgs {
     uint32_t lane_ws_bytes, lane_pathw, n_lanes;
     uint32_t lane_stride;        // 1: every lane of a wavefront runs walks; 64: one walk per wavefront (the few very long walks: a lane-per-walk
                                  // wavefront advances at the pace of its slowest lane, and these are thousands of wide steps long)
+    uint32_t leaves_in_lds;      // lane_stride 64 launches: the frontier's leaf buffers in LDS instead of the lane workspace
     uint32_t general_quorum_pct, general_max_wait;   // one-kernel form: lanes that need the general step wait for company (see wp_extend_kernel)
     uint32_t auto_dp;            // a failed walk with next == 0 goes to the DP stage in the same round
     WpDpItem* dp_items;

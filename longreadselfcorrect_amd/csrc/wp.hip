@@ -19,6 +19,10 @@
 
 namespace lrsc {
 
+#ifndef LRSC_WP_EXTEND_OCC
+#define LRSC_WP_EXTEND_OCC 2          // wavefronts per SIMD the extension kernel is compiled for (capi.cpp sizes its lanes to match)
+#endif
+
 // ---------------------------------------------------------------------------------------
 // geometry of one FM attempt (correctByFMExtension, PacBioSelfCorrectionProcess.cpp:162-190)
 // ---------------------------------------------------------------------------------------
@@ -307,7 +311,7 @@ __global__ __launch_bounds__(64) void wp_begin_kernel(FmIndexDev fm, WpArgs a)
 // extend: persistent lanes over a queue of walks
 // ---------------------------------------------------------------------------------------
 template <bool WIDE>
-__global__ __launch_bounds__(64, 2) void wp_extend_kernel(FmIndexDev fm, WpArgs a)
+__global__ __launch_bounds__(64, LRSC_WP_EXTEND_OCC) void wp_extend_kernel(FmIndexDev fm, WpArgs a)
 {
     using P = typename Lay<WIDE>::pos_t;
     __shared__ __attribute__((aligned(16))) uint32_t mtab[MaskTabSize<WIDE>::value];
@@ -324,7 +328,10 @@ __global__ __launch_bounds__(64, 2) void wp_extend_kernel(FmIndexDev fm, WpArgs 
     W.freqsOfKmerSize = a.freqs_of_kmer_size;
     const WpLaneLayout LL = wp_lane_layout(a.lbytes, a.lane_pathw);
     uint8_t* lws = a.lane_ws + (uint64_t)(owner ? lane_id : 0u) * a.lane_ws_bytes;
-    Leaf<P>* const leaf_base = reinterpret_cast<Leaf<P>*>(lws + LL.leaves);
+    // one walk per wavefront (lane_stride 64): the frontier's leaves live in LDS -- the general step is mostly leaf bookkeeping, and
+    // these launches are the walks with thousands of wide steps (every access here is a FLAT one, so the code is the same)
+    extern __shared__ __attribute__((aligned(16))) uint8_t wp_dyn_lds[];
+    Leaf<P>* const leaf_base = stride == 64u && a.leaves_in_lds ? reinterpret_cast<Leaf<P>*>(wp_dyn_lds) : reinterpret_cast<Leaf<P>*>(lws + LL.leaves);
     W.rings = reinterpret_cast<double*>(lws + LL.rings);
     W.results = reinterpret_cast<WalkResultRec*>(lws + LL.results);
     W.paths = reinterpret_cast<uint32_t*>(lws + LL.paths);
@@ -961,8 +968,9 @@ hipError_t launch_wp_extend(const FmIndexDev& fm, const WpArgs& a, hipStream_t s
     if(a.n_list == 0 || a.n_lanes == 0) return hipSuccess;
     const unsigned stride = a.lane_stride ? a.lane_stride : 1u;
     const unsigned nb = (unsigned)(((uint64_t)a.n_lanes * stride + 63) / 64);
-    if(fm.wide) hipLaunchKernelGGL(wp_extend_kernel<true>, dim3(nb), dim3(64), 0, stream, fm, a);
-    else        hipLaunchKernelGGL(wp_extend_kernel<false>, dim3(nb), dim3(64), 0, stream, fm, a);
+    const size_t lds = stride == 64u && a.leaves_in_lds ? (size_t)(32u + kMaxChildren) * a.lbytes : 0u;
+    if(fm.wide) hipLaunchKernelGGL(wp_extend_kernel<true>, dim3(nb), dim3(64), lds, stream, fm, a);
+    else        hipLaunchKernelGGL(wp_extend_kernel<false>, dim3(nb), dim3(64), lds, stream, fm, a);
     return hipGetLastError();
 }
 
