@@ -1617,8 +1617,8 @@ static int batch_correct_wp(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result* res,
     }
 
     if(verbose) {
-        HIP_TRY(ws.d_prof.reserve(16));
-        HIP_TRY(hipMemsetAsync(ws.d_prof.p, 0, 16 * sizeof(unsigned long long), ctx->stream));
+        HIP_TRY(ws.d_prof.reserve(32));                                      // [16..32): the long-gap walks' side launch on its own
+        HIP_TRY(hipMemsetAsync(ws.d_prof.p, 0, 32 * sizeof(unsigned long long), ctx->stream));
         a.prof = ws.d_prof.p;
     }
     int cus = 256;
@@ -1926,6 +1926,7 @@ static int batch_correct_wp(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result* res,
                 HIP_TRY(ws.d_ctr2.reserve(kCtrShards));
                 HIP_TRY(hipMemsetAsync(ws.d_ctr2.p, 0, kCtrShards * sizeof(DevCounters), ctx->stream));
                 xl.ctr = ws.d_ctr2.p;
+                if(a.prof) xl.prof = a.prof + 16;
                 HIP_TRY(side_begin());
                 if(!ws.ev_side_t0) HIP_TRY(hipEventCreate(&ws.ev_side_t0));
                 HIP_TRY(hipEventRecord(ws.ev_side_t0, ws.side[0]));
@@ -2059,14 +2060,20 @@ static int batch_correct_wp(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result* res,
     }
     (void)rounds_total;
     if(a.prof) {
-        unsigned long long pr[16];
+        unsigned long long prs[32];
         HIP_TRY(hipStreamSynchronize(ctx->stream));
-        HIP_TRY(hipMemcpy(pr, ws.d_prof.p, sizeof(pr), hipMemcpyDeviceToHost));
-        const double all = (double)pr[10], st = (double)std::max<unsigned long long>(pr[11], 1);
-        std::fprintf(stderr, "[lrsc] wp extension kernel, lane wall ticks: %.3g total, %.0f per step over %.3g steps; extendLeaves %.1f%% (refine %.1f%%, attempToExtend %.1f%% of which "
-                             "getFMIndexExtensions %.1f%%), PrunedBySeedSupport %.1f%%, materialise+commit %.1f%%, isTerminated %.1f%%, refill %.1f%%, finish %.1f%%; single-leaf fast steps %.1f%% of the steps in %.1f%% of the ticks\n",
-                     all, all / st, st, 100 * pr[0] / all, 100 * pr[1] / all, 100 * pr[2] / all, 100 * pr[3] / all, 100 * pr[4] / all, 100 * pr[5] / all, 100 * pr[6] / all,
-                     100 * pr[8] / all, 100 * pr[9] / all, 100 * pr[12] / st, 100 * pr[7] / all);
+        for(int i = 0; i < 2; ++i) HIP_TRY(hipStreamSynchronize(ws.side[i]));
+        HIP_TRY(hipMemcpy(prs, ws.d_prof.p, sizeof(prs), hipMemcpyDeviceToHost));
+        for(int part = 0; part < 2; ++part) {
+            const unsigned long long* pr = prs + 16 * part;
+            if(pr[10] == 0) continue;
+            const double all = (double)pr[10], st = (double)std::max<unsigned long long>(pr[11], 1);
+            std::fprintf(stderr, "[lrsc] wp extension kernel (%s), lane wall ticks: %.3g total, %.0f per step over %.3g steps; extendLeaves %.1f%% (refine %.1f%%, attempToExtend %.1f%% of which "
+                                 "getFMIndexExtensions %.1f%%), PrunedBySeedSupport %.1f%%, materialise+commit %.1f%%, isTerminated %.1f%%, refill %.1f%%, finish %.1f%%; single-leaf fast steps %.1f%% of the steps in %.1f%% of the ticks\n",
+                         part ? "long-gap walks, one per wavefront" : "bulk and later rounds",
+                         all, all / st, st, 100 * pr[0] / all, 100 * pr[1] / all, 100 * pr[2] / all, 100 * pr[3] / all, 100 * pr[4] / all, 100 * pr[5] / all, 100 * pr[6] / all,
+                         100 * pr[8] / all, 100 * pr[9] / all, 100 * pr[12] / st, 100 * pr[7] / all);
+        }
     }
     if(a.walk_log) b->walk_log_done = true;
 
