@@ -13,6 +13,11 @@
 #ifndef LRSC_WALK_NOINLINE
 #define LRSC_WALK_NOINLINE __noinline__
 #endif
+// Device code in the product.  tests/host_walk compiles this header with LRSC_WALK_FN = __host__ __device__ to run the very same
+// walk on the CPU against the oracle (test infrastructure: nothing in the product calls the host versions).
+#ifndef LRSC_WALK_FN
+#define LRSC_WALK_FN __device__
+#endif
 
 namespace lrsc {
 
@@ -22,7 +27,7 @@ constexpr uint64_t kNoKey = ~0ull;
 // bi-intervals of the 5-mer, the idmer (9-mer) and, inside the target seed, the minOverlap-mer starting at i,
 // each with findInterval's early exit; k-mer tables short-cut whole searches when a table of that size exists.
 template <bool WIDE>
-__device__ __forceinline__ void prepare_offset(const FmIndexDev& fm, const StrandC<typename Lay<WIDE>::pos_t>& sf,
+LRSC_WALK_FN __forceinline__ void prepare_offset(const FmIndexDev& fm, const StrandC<typename Lay<WIDE>::pos_t>& sf,
                                                const StrandC<typename Lay<WIDE>::pos_t>& sr, const uint32_t* __restrict__ mtab,
                                                const uint8_t* __restrict__ q, uint32_t i, uint32_t Lq, uint32_t trg0,
                                                uint32_t seedk, uint32_t mink, SortItem* it9f, SortItem* it9r, uint8_t* flags5,
@@ -64,7 +69,7 @@ __device__ __forceinline__ void prepare_offset(const FmIndexDev& fm, const Stran
 // configuration: 5, idmer = 9, minOverlap = 13): every emit is one table entry, so a rolling 2-bit window supplies the three
 // table indexes from ONE character load per offset (the generic path re-reads 5 + 9 + 13 characters per offset).
 template <bool WIDE>
-__device__ __forceinline__ int ktab_of(const FmIndexDev& fm, uint32_t k)
+LRSC_WALK_FN __forceinline__ int ktab_of(const FmIndexDev& fm, uint32_t k)
 {
     int t = -1;
     if(fm.ktab[0].k == k) t = 0;
@@ -75,7 +80,7 @@ __device__ __forceinline__ int ktab_of(const FmIndexDev& fm, uint32_t k)
     return t;
 }
 template <bool WIDE>
-__device__ __forceinline__ void ktab_entry(const FmIndexDev& fm, int t, uint32_t code, typename Lay<WIDE>::pos_t e[4])
+LRSC_WALK_FN __forceinline__ void ktab_entry(const FmIndexDev& fm, int t, uint32_t code, typename Lay<WIDE>::pos_t e[4])
 {
     using P = typename Lay<WIDE>::pos_t;
     const void* tabv = t == 0 ? fm.ktab[0].entries : t == 1 ? fm.ktab[1].entries : t == 2 ? fm.ktab[2].entries
@@ -91,7 +96,7 @@ __device__ __forceinline__ void ktab_entry(const FmIndexDev& fm, int t, uint32_t
     }
 }
 template <bool WIDE>
-__device__ LRSC_WALK_NOINLINE bool prepare_all_from_tables(const FmIndexDev& fm, const uint8_t* __restrict__ q, uint32_t Lq, uint32_t trg0, uint32_t seedk,
+LRSC_WALK_FN LRSC_WALK_NOINLINE bool prepare_all_from_tables(const FmIndexDev& fm, const uint8_t* __restrict__ q, uint32_t Lq, uint32_t trg0, uint32_t seedk,
                                                      uint32_t mink, SortItem* it9f, SortItem* it9r, uint8_t* flags5, typename Lay<WIDE>::pos_t* term)
 {
     using P = typename Lay<WIDE>::pos_t;
@@ -213,15 +218,15 @@ struct Walk {
     uint32_t max_front;               // widest frontier of the walk (profiling)
     uint64_t cyc_setup, cyc_loop;     // profiling: ticks spent building the trees/root and in the extension loop
     uint64_t* prof;                   // profiling: ReadOut::cyc_step of the read, or nullptr
-    __device__ __forceinline__ uint64_t tick() const { return prof ? __builtin_readcyclecounter() : 0; }
-    __device__ __forceinline__ void tock(int k, uint64_t t0) { if(prof) prof[k] += __builtin_readcyclecounter() - t0; }
+    LRSC_WALK_FN __forceinline__ uint64_t tick() const { return prof ? __builtin_readcyclecounter() : 0; }
+    LRSC_WALK_FN __forceinline__ void tock(int k, uint64_t t0) { if(prof) prof[k] += __builtin_readcyclecounter() - t0; }
     int error;
 
-    __device__ __forceinline__ IvT<P> upd(const StrandC<P>& s, uint32_t c, IvT<P> iv) { n_rank += 2; return update_interval<WIDE>(s, c, iv, mtab, n_blk); }
+    LRSC_WALK_FN __forceinline__ IvT<P> upd(const StrandC<P>& s, uint32_t c, IvT<P> iv) { n_rank += 2; return update_interval<WIDE>(s, c, iv, mtab, n_blk); }
 
     // findInterval of the leaf's suffix of length l on both strands (initialRootNode / refineSAInterval):
     // fwd = reverse(kmer) in the rbwt, rvc = revcomp(kmer) in the bwt; both consume kmer[0], kmer[1], ... in order
-    __device__ __forceinline__ void find_suffix_v(uint64_t slo, uint64_t shi, uint32_t l, P& flo, P& fhi, P& rlo, P& rhi)
+    LRSC_WALK_FN __forceinline__ void find_suffix_v(uint64_t slo, uint64_t shi, uint32_t l, P& flo, P& fhi, P& rlo, P& rhi)
     {
         auto ch = [&](uint32_t t) -> uint32_t {
             const uint32_t back = l - 1 - t;
@@ -236,7 +241,7 @@ struct Walk {
         n_rank += st.n_rank; n_blk += st.n_blk;
         flo = st.fwd.lo; fhi = st.fwd.hi; rlo = st.rvc.lo; rhi = st.rvc.hi;
     }
-    __device__ LRSC_WALK_NOINLINE void find_suffix(Leaf<P>& lf, uint32_t l)
+    LRSC_WALK_FN LRSC_WALK_NOINLINE void find_suffix(Leaf<P>& lf, uint32_t l)
     {
         P a, b, c, d;
         find_suffix_v(lf.suf_lo, lf.suf_hi, l, a, b, c, d);
@@ -245,7 +250,7 @@ struct Walk {
 
     // refineSAInterval (.cpp:355-369).  The leaves' searches are independent: four run side by side, so that a dependent rank step
     // of one leaf waits together with those of three others (a lane walks its frontier leaf by leaf otherwise)
-    __device__ LRSC_WALK_NOINLINE void refineSAInterval(Leaf<P>* leaves, uint32_t n, uint64_t newKmerSize)
+    LRSC_WALK_FN LRSC_WALK_NOINLINE void refineSAInterval(Leaf<P>* leaves, uint32_t n, uint64_t newKmerSize)
     {
         const uint32_t l = (uint32_t)newKmerSize;
         for(uint32_t i0 = 0; i0 < n; i0 += 4) {
@@ -298,7 +303,7 @@ struct Walk {
     // The pair is findBiInterval of x = revcomp(startkmer) with the strands' roles swapped (f walks the bwt with c, r the
     // rbwt with 3 - c, both from the k-mer's last character backwards), so a k-mer table entry of x's first characters
     // -- same early-exit semantics per strand -- replaces that many dependent rank steps.
-    __device__ __forceinline__ void select_first(uint64_t slo, uint64_t shi, uint32_t U, uint32_t Lw, IvT<P>& f, IvT<P>& r)
+    LRSC_WALK_FN __forceinline__ void select_first(uint64_t slo, uint64_t shi, uint32_t U, uint32_t Lw, IvT<P>& f, IvT<P>& r)
     {
         auto sc = [&](uint32_t t) -> uint32_t {                 // suf_char(lf, U, t)
             const uint32_t back = U - 1 - t;
@@ -325,14 +330,14 @@ struct Walk {
             if(fb && rb) break;
         }
     }
-    __device__ __forceinline__ void select_next(uint64_t slo, uint64_t shi, uint32_t U, uint32_t t, IvT<P>& f, IvT<P>& r)
+    LRSC_WALK_FN __forceinline__ void select_next(uint64_t slo, uint64_t shi, uint32_t U, uint32_t t, IvT<P>& f, IvT<P>& r)
     {
         const uint32_t back = U - 1 - t;
         const uint32_t b = back < 32 ? (uint32_t)(slo >> (2 * back)) & 3u : (uint32_t)(shi >> (2 * (back - 32))) & 3u;
         f = upd(sR, b, f);                           // no validity check here (.cpp:317-318)
         r = upd(sF, 3u - b, r);
     }
-    __device__ LRSC_WALK_NOINLINE uint64_t SelectFreqsOfrange(uint64_t LowerBound, uint64_t UpperBound, Leaf<P>* leaves, uint32_t n)
+    LRSC_WALK_FN LRSC_WALK_NOINLINE uint64_t SelectFreqsOfrange(uint64_t LowerBound, uint64_t UpperBound, Leaf<P>* leaves, uint32_t n)
     {
         int tempmaxfmfreqs = 0;
         const uint32_t U = (uint32_t)UpperBound, Lw = (uint32_t)LowerBound;
@@ -361,7 +366,7 @@ struct Walk {
         return UpperBound;
     }
     // the same for a frontier of one leaf, on values (the leaf's tf* scratch fields are write-only outside this function)
-    __device__ __forceinline__ uint64_t SelectFreqsOfrange1(uint64_t LowerBound, uint64_t UpperBound, uint64_t slo, uint64_t shi)
+    LRSC_WALK_FN __forceinline__ uint64_t SelectFreqsOfrange1(uint64_t LowerBound, uint64_t UpperBound, uint64_t slo, uint64_t shi)
     {
         const uint32_t U = (uint32_t)UpperBound, Lw = (uint32_t)LowerBound;
         IvT<P> f, r;
@@ -379,7 +384,7 @@ struct Walk {
     }
 
     // isInsufficientFreqs (.cpp:334-352) over the children attempToExtend has just made: it counted those above the threshold
-    __device__ bool isInsufficientFreqs(uint64_t highfreqscount, uint32_t n)
+    LRSC_WALK_FN bool isInsufficientFreqs(uint64_t highfreqscount, uint32_t n)
     {
         if(highfreqscount == 0) return true;
         else if(highfreqscount <= 2 && n >= 5) return true;
@@ -388,7 +393,7 @@ struct Walk {
     }
 
     // ---- ismatchedbykmer (.cpp:787-821): any 5-mer hit of the extended path within the indel window --------
-    __device__ bool ismatchedbykmer(uint32_t code5, bool fvalid, bool rvalid)
+    LRSC_WALK_FN bool ismatchedbykmer(uint32_t code5, bool fvalid, bool rvalid)
     {
         const uint64_t startSeedIdx = (uint64_t)(((int)currentLength - (int)maxIndelSize) > 0 ? ((int)currentLength - (int)maxIndelSize) : 0);
         const uint64_t largeSeedIdx = currentLength + maxIndelSize;
@@ -403,11 +408,11 @@ struct Walk {
 
     // ---- getFMIndexExtensions (.cpp:667-784): returns a bit mask of accepted bases, fills ext[] -------------
     struct Ext { IvT<P> f, r; int freq; };
-    __device__ __forceinline__ uint32_t getFMIndexExtensions(const Leaf<P>& lf, Ext ext[4], uint64_t& totalcount_out)
+    LRSC_WALK_FN __forceinline__ uint32_t getFMIndexExtensions(const Leaf<P>& lf, Ext ext[4], uint64_t& totalcount_out)
     {
         return getFMIndexExtensions_v(lf.flo, lf.fhi, lf.rlo, lf.rhi, lf.tailLetterCount, lf.suf_lo, ext, totalcount_out);
     }
-    __device__ __forceinline__ uint32_t getFMIndexExtensions_v(P lf_flo, P lf_fhi, P lf_rlo, P lf_rhi, uint32_t lf_tailLetterCount, uint64_t lf_suf_lo,
+    LRSC_WALK_FN __forceinline__ uint32_t getFMIndexExtensions_v(P lf_flo, P lf_fhi, P lf_rlo, P lf_rhi, uint32_t lf_tailLetterCount, uint64_t lf_suf_lo,
                                                                Ext ext[4], uint64_t& totalcount_out)
     {
         struct { P flo, fhi, rlo, rhi; uint32_t tailLetterCount; uint64_t suf_lo; } lf{lf_flo, lf_fhi, lf_rlo, lf_rhi, lf_tailLetterCount, lf_suf_lo};
@@ -459,14 +464,14 @@ struct Walk {
         return mask;
     }
 
-    __device__ void free_leaf_slots(const Leaf<P>& lf)
+    LRSC_WALK_FN void free_leaf_slots(const Leaf<P>& lf)
     {
         ring_free |= 1u << lf.ring;
         path_free |= 1u << lf.path;
     }
 
     // ---- attempToExtend (.cpp:373-465) + updateLeaves (:468-488) -------------------------------------------
-    __device__ void attempToExtend()
+    LRSC_WALK_FN void attempToExtend()
     {
         double minimumErrorRate = 1;
         for(uint32_t i = 0; i < n_cur; i += 4) {                 // four loads in flight, same comparisons in the same order
@@ -530,7 +535,7 @@ struct Walk {
     }
 
     // ---- extendLeaves (.cpp:239-278) ------------------------------------------------------------------------
-    __device__ void extendLeaves()
+    LRSC_WALK_FN void extendLeaves()
     {
         n_nxt = 0;
         uint64_t t = tick();
@@ -565,11 +570,11 @@ struct Walk {
     }
 
     // ---- isSupportedByNewSeed (.cpp:566-635) ------------------------------------------------------------------
-    __device__ LRSC_WALK_NOINLINE bool isSupportedByNewSeed(Leaf<P>& nd, uint64_t smallSeedIdx, uint64_t largeSeedIdx)
+    LRSC_WALK_FN LRSC_WALK_NOINLINE bool isSupportedByNewSeed(Leaf<P>& nd, uint64_t smallSeedIdx, uint64_t largeSeedIdx)
     {
         return seed_support_core(nd, smallSeedIdx, largeSeedIdx);
     }
-    __device__ __forceinline__ bool seed_support_core(Leaf<P>& nd, uint64_t smallSeedIdx, uint64_t largeSeedIdx)
+    LRSC_WALK_FN __forceinline__ bool seed_support_core(Leaf<P>& nd, uint64_t smallSeedIdx, uint64_t largeSeedIdx)
     {
         const uint64_t seedIdxOffset = nd.lastOverlapLen < currentLength - seedSize ? (uint64_t)seedSize : currentLength - nd.lastOverlapLen;
         const uint64_t cand = nd.lastSeedIdx + seedIdxOffset;
@@ -613,7 +618,7 @@ struct Walk {
     }
 
     // seedSize-mer code of m_query at offset i (first character in the high bits)
-    __device__ __forceinline__ uint32_t kmer_code(uint32_t i) const
+    LRSC_WALK_FN __forceinline__ uint32_t kmer_code(uint32_t i) const
     {
         uint32_t c = 0;
         for(uint32_t t = 0; t < seedSize; ++t) c = (c << 2) | q[i + t];
@@ -621,7 +626,7 @@ struct Walk {
     }
 
     // ---- computeErrorRate (.cpp:638-664) ------------------------------------------------------------------
-    __device__ double computeErrorRate(Leaf<P>& nd, const double* parent_ring)
+    LRSC_WALK_FN double computeErrorRate(Leaf<P>& nd, const double* parent_ring)
     {
         double matchedLen = (double)nd.totalSeeds + seedSize - 1;
         matchedLen += nd.numRedeemSeed;
@@ -641,7 +646,7 @@ struct Walk {
 
     // ---- PrunedBySeedSupport (.cpp:491-563) ------------------------------------------------------------------
     template <bool INLINE>
-    __device__ __forceinline__ void prune_leaf(Leaf<P>& leaf, const double* pring, uint64_t currSeedIdx, uint64_t smallSeedIdx, uint64_t largeSeedIdx)
+    LRSC_WALK_FN __forceinline__ void prune_leaf(Leaf<P>& leaf, const double* pring, uint64_t currSeedIdx, uint64_t smallSeedIdx, uint64_t largeSeedIdx)
     {
         bool isNewSeedFound = false;
         if(currentLength - leaf.lastOverlapLen > seedSize || currentLength - leaf.lastOverlapLen <= 1) {
@@ -661,7 +666,7 @@ struct Walk {
         const double currErrorRate = computeErrorRate(leaf, pring);
         if(currErrorRate > errorRate) leaf.alive = 0;
     }
-    __device__ void PrunedBySeedSupport()
+    LRSC_WALK_FN void PrunedBySeedSupport()
     {
         const uint64_t currSeedIdx = currentLength - seedSize;
         const uint64_t indelOffset = seedSize + maxIndelSize;
@@ -678,7 +683,7 @@ struct Walk {
     }
 
     // ---- isTerminated for one leaf (.cpp:825-878); path given as (words, len) + optional extra char ------------
-    __device__ LRSC_WALK_NOINLINE void terminated_leaf(Leaf<P>& lf, const uint32_t* pw, uint32_t plen, int extra)
+    LRSC_WALK_FN LRSC_WALK_NOINLINE void terminated_leaf(Leaf<P>& lf, const uint32_t* pw, uint32_t plen, int extra)
     {
         const bool fvalid = lf.flo <= lf.fhi, rvalid = lf.rlo <= lf.rhi;
         // A non-empty interval of a k-mer K lies inside the interval of a k-mer w with |w| <= |K| only if K ends with w (fwd strand:
@@ -722,7 +727,7 @@ struct Walk {
     // ---- one walk = begin() + step() until it returns false + finish() ------------------------------------------
     // (split so that the persistent kernel can keep all lanes of a wavefront in the step loop: a lane whose walk
     //  ended sets up its next one while the others wait, instead of idling until the longest walk of the wave ends)
-    __device__ int run(uint32_t* out_len, uint32_t* out_words, uint32_t* out_match_i)
+    LRSC_WALK_FN int run(uint32_t* out_len, uint32_t* out_words, uint32_t* out_match_i)
     {
         begin();
         while(step()) {}
@@ -734,7 +739,7 @@ struct Walk {
 
     // The constructor's per-walk tables that stay fixed during the walk (.cpp:90-94,127-152 after the bulk look-ups of
     // prepare_offset): the interval "trees" as sorted k-mer chains, the 5-mer chains, the isTerminated filter.
-    __device__ LRSC_WALK_NOINLINE void begin_static()
+    LRSC_WALK_FN LRSC_WALK_NOINLINE void begin_static()
     {
         // --- interval "trees": compact the valid 9-mer entries (emplace_back order), introsort, chain by k-mer ---
         auto build9 = [&](SortItem* it, uint32_t n_all, uint16_t* head, uint16_t* next) -> uint32_t {
@@ -784,7 +789,7 @@ struct Walk {
 
     // --- root (initialRootNode, .cpp:108-124; leafInfo ctor, .h:156-171).  root_iv: the root k-mer's bi-interval {fwd.lo,
     //     fwd.hi, rvc.lo, rvc.hi} when a preparation pass has already searched it, nullptr to search it here ---
-    __device__ LRSC_WALK_NOINLINE void begin_root(const P* root_iv)
+    LRSC_WALK_FN LRSC_WALK_NOINLINE void begin_root(const P* root_iv)
     {
         ring_free = 0xFFFFFFFEu; path_free = 0xFFFFFFFEu;
         Leaf<P>& root = cur[0];
@@ -813,7 +818,7 @@ struct Walk {
         ended = false;
     }
 
-    __device__ LRSC_WALK_NOINLINE void begin()
+    LRSC_WALK_FN LRSC_WALK_NOINLINE void begin()
     {
         const uint64_t t_run0 = __builtin_readcyclecounter();
         begin_static();
@@ -828,16 +833,16 @@ struct Walk {
     // general step (extendLeaves / PrunedBySeedSupport / the commit in step_body); a step that is not of the simple kind -- no
     // accepted base, more than one -- is handed to the general code BEFORE it has had any effect.
     // ---------------------------------------------------------------------------------------------------------
-    __device__ __forceinline__ bool can_fast() const { return !ended && !error && n_cur == 1; }
-    __device__ __forceinline__ void enter_fast(Leaf<P>& L, uint32_t& pw)
+    LRSC_WALK_FN __forceinline__ bool can_fast() const { return !ended && !error && n_cur == 1; }
+    LRSC_WALK_FN __forceinline__ void enter_fast(Leaf<P>& L, uint32_t& pw)
     {
         L = cur[0];
         pw = (L.path_len & 15u) ? paths[(uint64_t)L.path * pathw + (L.path_len >> 4)] : 0u;
     }
-    __device__ __forceinline__ void leave_fast(const Leaf<P>& L) { cur[0] = L; }
+    LRSC_WALK_FN __forceinline__ void leave_fast(const Leaf<P>& L) { cur[0] = L; }
     // 1: step done, the frontier is still the one leaf in L;  0: extendOverlap's loop is over (L written back, finish() decides);
     // 2: not a simple step -- nothing has happened, L written back: run the general step()
-    __device__ __forceinline__ int step_fast(Leaf<P>& L, uint32_t& pw)
+    LRSC_WALK_FN __forceinline__ int step_fast(Leaf<P>& L, uint32_t& pw)
     {
         if(!(currentLength <= maxLength)) { leave_fast(L); return 0; }
         // attempToExtend's trimming never fires for one leaf unless its local error rate is >= 1 (the minimum starts at 1): general code
@@ -912,7 +917,7 @@ struct Walk {
     }
 
     // one iteration of extendOverlap's loop (.cpp:155-211); false when the loop is over (or on an internal error)
-    __device__ bool step()
+    LRSC_WALK_FN bool step()
     {
         if(ended || error || !(n_cur != 0 && n_cur <= maxLeaves && currentLength <= maxLength)) return false;
         leaf_steps += n_cur;
@@ -926,7 +931,7 @@ struct Walk {
         return true;
     }
 
-    __device__ void step_body()
+    LRSC_WALK_FN void step_body()
     {
         {
             uint64_t t = tick();
@@ -1002,7 +1007,7 @@ struct Walk {
         }
     }
 
-    __device__ LRSC_WALK_NOINLINE int finish(uint32_t* out_len, uint32_t* out_words, uint32_t* out_match_i)
+    LRSC_WALK_FN LRSC_WALK_NOINLINE int finish(uint32_t* out_len, uint32_t* out_words, uint32_t* out_match_i)
     {
         if(error) return error;
         // --- findTheBestPath (.cpp:214-236) ---
