@@ -1498,6 +1498,7 @@ struct WpScratch {
     hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t ev_side[2] = {nullptr, nullptr}, ev_ready = nullptr;
     DevBuf<unsigned long long> d_prof;
+    DevBuf<uint8_t> d_coop, d_coop_side;
     DevBuf<WpSched> d_sched;
     DevBuf<uint32_t> d_sched_lists[2];
     DevArena persist;
@@ -1639,6 +1640,8 @@ static int batch_correct_wp(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result* res,
 
     uint32_t mid_stride = 64, long_mode = 0;
     if(const char* ev = std::getenv("LRSC_WP_LONG_MODE")) long_mode = (uint32_t)std::atoi(ev);
+    bool coop_helpers = false;                       // experiment: run-ahead helper lanes in the one-walk-per-wavefront launches
+    if(const char* ev = std::getenv("LRSC_WP_COOP")) coop_helpers = std::atoi(ev) != 0;
     uint32_t leaves_in_lds = 0;                      // measured: 77.5-77.7 vs 79.1-80.3 corrected Mbases/s with the leaves in LDS (the DP stage beside it wants the LDS)
     if(const char* ev = std::getenv("LRSC_WP_LEAVES_LDS")) leaves_in_lds = std::atoi(ev) != 0;
     uint32_t long_first_div = 8;
@@ -1668,6 +1671,13 @@ static int batch_correct_wp(lrsc_ctx* ctx, lrsc_batch* b, lrsc_read_result* res,
         x.queue = ws.d_small.p + 8 + which;
         e2 = hipMemsetAsync(x.queue, 0, sizeof(uint32_t), st);
         if(e2 != hipSuccess) return e2;
+        if(coop_helpers && stride == 64) {
+            // one walk per wavefront with run-ahead helper lanes (wp_extend_coop_kernel): a private leaf buffer per lane
+            DevBuf<uint8_t>& cb = which ? ws.d_coop_side : ws.d_coop;
+            e2 = cb.reserve(lanes * 64 * kWpCoopLeaves * lbytes);
+            if(e2 != hipSuccess) return e2;
+            return launch_wp_extend_coop(ctx->fm, x, cb.p, st);
+        }
         return launch_wp_extend(ctx->fm, x, st);
     };
 

@@ -916,6 +916,15 @@ struct Walk {
         return 1;
     }
 
+    // The memory-bound front of a step (extension + seed support) on whatever frontier `cur` points at, nothing committed: a helper
+    // lane of wp_extend_coop_kernel runs it on a private copy of ONE leaf ahead of the owner's real step, to have the rank blocks,
+    // table entries and 9-mer chains that leaf needs in the caches.  Writes: cur / nxt (private there) and this object's scalars.
+    LRSC_WALK_FN void warm()
+    {
+        extendLeaves();
+        if(!error) PrunedBySeedSupport();
+    }
+
     // one iteration of extendOverlap's loop (.cpp:155-211); false when the loop is over (or on an internal error)
     LRSC_WALK_FN bool step()
     {

@@ -179,6 +179,7 @@ struct WpArgs {
     unsigned long long* prof;    // LRSC_CORRECT_PROFILE: 16 tick totals of the extension kernel (per-lane wall ticks summed over lanes)
 };
 
+constexpr uint32_t kWpCoopLeaves = 8;   // wp_coop.hip: a helper lane's private frontier (its leaf + up to four children, with room to spare)
 constexpr uint32_t kWpPathwSmall = 64, kWpPathwMid = 256;
 
 // ---- the two-class schedule of the extension (wp_fast_kernel / wp_general_kernel) ---------------------------------------------
@@ -224,6 +225,7 @@ hipError_t launch_wp_plan(const WpArgs& a, hipStream_t stream);
 hipError_t launch_wp_materialize(const WpArgs& a, hipStream_t stream);
 hipError_t launch_wp_prepare(const FmIndexDev& fm, const WpArgs& a, hipStream_t stream);
 hipError_t launch_wp_begin(const FmIndexDev& fm, const WpArgs& a, hipStream_t stream);
+hipError_t launch_wp_extend_coop(const FmIndexDev& fm, const WpArgs& a, uint8_t* coop_ws, hipStream_t stream);   // wp_coop.hip
 hipError_t launch_wp_extend(const FmIndexDev& fm, const WpArgs& a, hipStream_t stream);
 // one round of the two-class schedule: fast kernel, list rotation, general kernel, list rotation
 hipError_t launch_wp_sched_init(const WpSchedArgs& sa, uint32_t* list_storage, uint32_t n_fresh, hipStream_t stream);
