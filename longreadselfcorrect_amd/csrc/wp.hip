@@ -11,6 +11,16 @@
 //   wp_dp_collect_kernel   DP answers -> slots
 //   wp_stitch_kernel       wavefront per read: initCorrect's chain (PacBioSelfCorrectionProcess.cpp:78-152) over the finished
 //                          walks; a walk whose assumed source k-mer is not the true tail of the accumulated string is re-queued
+//
+// This translation unit compiles walk_device.h with ALL of the walk inlined into its kernels (the two defines below).  With the
+// big pieces of the walk as calls (the header's default, kept by extend.hip and wp_coop.hip) the Walk object's address escapes into
+// every call as `this`, so the object lives in scratch memory and every field access is a memory round trip of its own -- for a
+// lane that has nothing else in flight, most of a step's latency.  Counted on the ISA of wp_extend_kernel's call tree (narrow
+// layout): 1 864 FLAT + 1 012 scratch memory instructions with calls, 633 + 364 all inline, for 16 % more instructions (29 k).
+// Same source, same arithmetic in the same order: on the bench workload (4.79 M walks per two steps, both rank-block layouts) every
+// counter down to the number of rank queries is identical, and the default flow goes from 78 to 93 corrected Mbases/s.
+#define LRSC_WALK_FN __device__ __forceinline__
+#define LRSC_WALK_NOINLINE
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
